@@ -1,0 +1,164 @@
+/*
+ * lmg.h -- C ABI of the MI355X (gfx950) multigrid V-cycle kernels.
+ *
+ * This is the drop-in boundary for the hot path of claudiotomasi/LearnMultigrid
+ * (learn_multigrid/solvers/Multigrid.py:36-124).  The reference is pure Python
+ * and has no FFI of its own; each entry point below replaces one SciPy / pyamg
+ * call made on that path and cites it (paths relative to /root/reference).
+ * INTEGRATION.md shows the ctypes binding a maintainer adds on the Python side.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++ / torch types.
+ *   - Every `const T*` / `T*` named d_* or documented "device" is a DEVICE pointer
+ *     owned by the caller; the library never allocates, frees or synchronises
+ *     inside a launch function (graph-capture safe) -- scratch is passed in.
+ *   - CSR: int32 rowptr[n+1], int32 colidx[nnz], fp64 vals[nnz]; array bases must
+ *     be 16-byte aligned (LMG_ERR_ALIGN otherwise).  Rows are accumulated in
+ *     storage order with separate multiply and add roundings (no FMA contraction),
+ *     which makes SpMV / Jacobi / Gauss-Seidel bit-identical to SciPy's
+ *     csr_matvec and to pyamg's sweep on sorted CSR.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - Return value: LMG_OK (0) or a negative lmg_status; no exceptions cross the ABI.
+ */
+#ifndef LMG_H
+#define LMG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LMG_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+    LMG_OK = 0,
+    LMG_ERR_ARG = -1,       /* null pointer / negative size / bad enum            */
+    LMG_ERR_ALIGN = -2,     /* array base not 16-byte aligned                     */
+    LMG_ERR_LAUNCH = -3,    /* HIP reported a launch / runtime error              */
+    LMG_ERR_CAPACITY = -4,  /* a row exceeds what the kernel's LDS tile can hold  */
+    LMG_ERR_NODEVICE = -5   /* no HIP device visible                              */
+} lmg_status;
+
+int lmg_version(void);
+const char *lmg_status_string(int status);
+/* Number of visible HIP devices, or a negative lmg_status. */
+int lmg_device_count(void);
+
+/* Runtime tuning knobs (kernel variant selection; used by bench.py for A/B runs).
+ *   key "sweep_rpt"  : rows per thread of the sweep kernels, one of 1, 2, 4.       */
+int lmg_tune_set(const char *key, int value);
+int lmg_tune_get(const char *key);
+
+/* ---- fine-level sweeps ---------------------------------------------------------
+ * Number of fp64 partial sums lmg_csr_residual_norm2 / lmg_dot need as scratch. */
+int64_t lmg_partials_count(int64_t n);
+
+/* r = b - A x  and  *d_norm2 = sum_i r_i^2 (deterministic two-stage reduction).
+ * Replaces `rhs - A.dot(u)` + `np.linalg.norm` (Multigrid.py:62-63,:90; Jacobi.py:28-29).
+ * d_r may be NULL (norm only); d_partials/d_norm2 may both be NULL (residual only). */
+int lmg_csr_residual_norm2(int64_t n, int64_t nnz, const int32_t *d_rowptr, const int32_t *d_colidx,
+                           const double *d_vals, const double *d_x, const double *d_b, double *d_r,
+                           double *d_partials, double *d_norm2, void *stream);
+
+/* x_out = x_in + omega * ((1/a_ii) * (b - A x_in)); rows without a diagonal copy x_in.
+ * omega = 1 is the reference update `solution += inv_d * residual_vector`
+ * (Jacobi.py:22-35).  x_out must not alias x_in. */
+int lmg_csr_jacobi(int64_t n, int64_t nnz, const int32_t *d_rowptr, const int32_t *d_colidx,
+                   const double *d_vals, const double *d_x_in, const double *d_b, double omega,
+                   double *d_x_out, void *stream);
+
+/* y = alpha * (A x) + beta * y  (beta == 0 never reads y).
+ * Restriction  r_c = P^T r  (Multigrid.py:93) with A := R = P^T stored as CSR;
+ * prolongation u += P e     (Multigrid.py:115) with alpha = beta = 1. */
+int lmg_csr_spmv(int64_t n_rows, int64_t nnz, const int32_t *d_rowptr, const int32_t *d_colidx,
+                 const double *d_vals, const double *d_x, double *d_y, double alpha, double beta,
+                 void *stream);
+
+/* ---- Gauss-Seidel ---------------------------------------------------------------
+ * One independent set: for every i in d_rows, in place,
+ *     x_i = (b_i - sum_{j != i} a_ij x_j) / a_ii      (skipped when a_ii == 0)
+ * -- the row update of pyamg's gauss_seidel (called at Multigrid.py:88,:121).  The rows
+ * of one call must be mutually independent in the pattern of A + A^T. */
+int lmg_csr_gs_rows(const int32_t *d_rowptr, const int32_t *d_colidx, const double *d_vals,
+                    double *d_x, const double *d_b, const int32_t *d_rows, int64_t nrows,
+                    void *stream);
+
+/* `sweeps` sweeps over a schedule of `nsets` independent sets executed in order
+ * (level schedule => exact lexicographic forward Gauss-Seidel; colour classes =>
+ * multicolour Gauss-Seidel).  d_set_ptr / h_set_ptr are the same nsets+1 offsets into
+ * d_set_rows on device and host.  max_set = largest set size. */
+int lmg_csr_gs_schedule(const int32_t *d_rowptr, const int32_t *d_colidx, const double *d_vals,
+                        double *d_x, const double *d_b, const int32_t *d_set_rows,
+                        const int32_t *d_set_ptr, const int32_t *h_set_ptr, int64_t nsets,
+                        int64_t max_set, int sweeps, void *stream);
+
+/* HOST helpers (host pointers, run on the CPU at setup time).
+ * level[i] = 1 + max(level[j] : j < i adjacent to i in A + A^T), 0 if none: rows of equal
+ * level are independent, executing levels in order IS the lexicographic sweep.
+ * Returns the number of levels (>= 0) or a negative lmg_status. */
+int64_t lmg_host_gs_levels(int64_t n, const int32_t *h_rowptr, const int32_t *h_colidx,
+                           int32_t *h_level_out);
+/* Greedy natural-order colouring of A + A^T; returns the number of colours. */
+int64_t lmg_host_greedy_colors(int64_t n, const int32_t *h_rowptr, const int32_t *h_colidx,
+                               int32_t *h_color_out);
+
+/* ---- vectors --------------------------------------------------------------------*/
+int lmg_axpby(int64_t n, double alpha, const double *d_x, double beta, double *d_y, void *stream);
+int lmg_copy(int64_t n, const double *d_src, double *d_dst, void *stream);
+int lmg_zero(int64_t n, double *d_x, void *stream);
+int lmg_dot(int64_t n, const double *d_x, const double *d_y, double *d_partials, double *d_out,
+            void *stream);
+/* buf[k] = x[idx[k]] (halo pack) and x[idx[k]] = buf[k] (unpack). */
+int lmg_gather(int64_t n, const int32_t *d_idx, const double *d_x, double *d_buf, void *stream);
+int lmg_scatter(int64_t n, const int32_t *d_idx, const double *d_buf, double *d_x, void *stream);
+
+/* ---- coarsest level --------------------------------------------------------------
+ * y = M x for a dense row-major n x m matrix: applies a pre-factored coarse operator
+ * (M = A_L^-1 computed once at setup) in place of the per-cycle SuperLU
+ * `spsolve(A_coarse, res_coarse)` of Multigrid.py:106. */
+int lmg_dense_gemv(int64_t n, int64_t m, const double *d_M, const double *d_x, double *d_y,
+                   void *stream);
+
+/* ---- Galerkin product (SpGEMM)  C = A * B -----------------------------------------
+ * Replaces SciPy's csr_matmat behind `i.T @ A @ i` (Multigrid.py:97-98), evaluated as
+ * (R A) P like SciPy does.  Row-wise Gustavson with an expand / stable-sort / in-order
+ * compress per row, so C has sorted rows and every c_ik is accumulated in the order of
+ * the products a_ij*b_jk as SciPy traverses them.
+ *   1. lmg_spgemm_count     : d_row_products[i] = sum_j nnz(B_j)  (upper bound of nnz(C_i))
+ *   2. lmg_spgemm_symbolic  : d_c_rownnz[i] = nnz(C_i)            (needs step 1)
+ *      -- caller turns d_c_rownnz into d_c_rowptr with lmg_exclusive_scan_i32 --
+ *   3. lmg_spgemm_numeric   : fills d_c_colidx / d_c_vals.
+ * Rows whose product count exceeds LMG_SPGEMM_MAX_ROW_PRODUCTS return LMG_ERR_CAPACITY. */
+#define LMG_SPGEMM_MAX_ROW_PRODUCTS 8192
+int lmg_spgemm_count(int64_t a_rows, const int32_t *d_a_rowptr, const int32_t *d_a_colidx,
+                     const int32_t *d_b_rowptr, int32_t *d_row_products, int32_t *d_max_products,
+                     void *stream);
+int lmg_spgemm_symbolic(int64_t a_rows, const int32_t *d_a_rowptr, const int32_t *d_a_colidx,
+                        const int32_t *d_b_rowptr, const int32_t *d_b_colidx,
+                        const int32_t *d_row_products, int32_t max_products,
+                        int32_t *d_c_rownnz, void *stream);
+int lmg_spgemm_numeric(int64_t a_rows, const int32_t *d_a_rowptr, const int32_t *d_a_colidx,
+                       const double *d_a_vals, const int32_t *d_b_rowptr,
+                       const int32_t *d_b_colidx, const double *d_b_vals,
+                       const int32_t *d_row_products, int32_t max_products,
+                       const int32_t *d_c_rowptr, int32_t *d_c_colidx, double *d_c_vals,
+                       void *stream);
+/* out[0] = 0, out[i+1] = in[0] + ... + in[i]  (n inputs, n+1 outputs).
+ * d_scratch holds lmg_scan_scratch_count(n) int32 values. */
+int64_t lmg_scan_scratch_count(int64_t n);
+int lmg_exclusive_scan_i32(int64_t n, const int32_t *d_in, int32_t *d_out, int32_t *d_scratch,
+                           void *stream);
+
+/* ---- hipGraph capture of a launch sequence (one V-cycle) -----------------------------
+ * begin/end bracket launches issued on `stream`; end returns an opaque executable graph. */
+int lmg_graph_begin(void *stream);
+int lmg_graph_end(void *stream, void **graph_exec_out);
+int lmg_graph_launch(void *graph_exec, void *stream);
+int lmg_graph_destroy(void *graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LMG_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of the C ABI declared in include/lmg.h (liblmg_hip.so, gfx950 only).
+
+There is NO fallback: if the shared library is missing or a call returns a negative
+status this module raises.  Nothing here (or anywhere in learnmultigrid_amd) imports
+the CPU oracle.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblmg_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_c = ctypes
+_i64, _i32, _f64, _p, _cp = _c.c_int64, _c.c_int32, _c.c_double, _c.c_void_p, _c.c_char_p
+
+# name -> (restype, argtypes).  One row per symbol of include/lmg.h; tests/test_abi.py
+# cross-checks this table against the header.
+SIGNATURES = {
+    "lmg_version": (_c.c_int, []),
+    "lmg_status_string": (_cp, [_c.c_int]),
+    "lmg_device_count": (_c.c_int, []),
+    "lmg_tune_set": (_c.c_int, [_cp, _c.c_int]),
+    "lmg_tune_get": (_c.c_int, [_cp]),
+    "lmg_partials_count": (_i64, [_i64]),
+    "lmg_csr_residual_norm2": (_c.c_int, [_i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "lmg_csr_jacobi": (_c.c_int, [_i64, _i64, _p, _p, _p, _p, _p, _f64, _p, _p]),
+    "lmg_csr_spmv": (_c.c_int, [_i64, _i64, _p, _p, _p, _p, _p, _f64, _f64, _p]),
+    "lmg_csr_gs_rows": (_c.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p]),
+    "lmg_csr_gs_schedule": (_c.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _c.c_int, _p]),
+    "lmg_host_gs_levels": (_i64, [_i64, _p, _p, _p]),
+    "lmg_host_greedy_colors": (_i64, [_i64, _p, _p, _p]),
+    "lmg_axpby": (_c.c_int, [_i64, _f64, _p, _f64, _p, _p]),
+    "lmg_copy": (_c.c_int, [_i64, _p, _p, _p]),
+    "lmg_zero": (_c.c_int, [_i64, _p, _p]),
+    "lmg_dot": (_c.c_int, [_i64, _p, _p, _p, _p, _p]),
+    "lmg_gather": (_c.c_int, [_i64, _p, _p, _p, _p]),
+    "lmg_scatter": (_c.c_int, [_i64, _p, _p, _p, _p]),
+    "lmg_dense_gemv": (_c.c_int, [_i64, _i64, _p, _p, _p, _p]),
+    "lmg_spgemm_count": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p]),
+    "lmg_spgemm_symbolic": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _i32, _p, _p]),
+    "lmg_spgemm_numeric": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
+    "lmg_scan_scratch_count": (_i64, [_i64]),
+    "lmg_exclusive_scan_i32": (_c.c_int, [_i64, _p, _p, _p, _p]),
+    "lmg_graph_begin": (_c.c_int, [_p]),
+    "lmg_graph_end": (_c.c_int, [_p, _c.POINTER(_p)]),
+    "lmg_graph_launch": (_c.c_int, [_p, _p]),
+    "lmg_graph_destroy": (_c.c_int, [_p]),
+}
+
+_lib = None
+
+
+class LmgError(RuntimeError):
+    pass
+
+
+def build(force=False, quiet=True):
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL if quiet else None)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises LmgError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LmgError(
+                "liblmg_hip.so not found at %s -- build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if L.lmg_version() < 100:
+            raise LmgError("liblmg_hip.so is older than the Python package")
+        _lib = L
+    return _lib
+
+
+def check(status, what=""):
+    if status < 0:
+        msg = lib().lmg_status_string(int(status)).decode()
+        raise LmgError("%s failed: %s (status %d)" % (what or "lmg call", msg, status))
+    return status

@@ -1,0 +1,180 @@
+// Gauss-Seidel on gfx950.
+//
+// The reference's shipped smoother is pyamg's forward lexicographic sweep
+// (Multigrid.py:88,:121): inherently sequential.  It is reproduced EXACTLY by level
+// scheduling: rows are grouped into sets that are mutually independent in the pattern
+// of A + A^T (dependencies AND anti-dependencies), sets are executed in order, and each
+// row does the pyamg update in storage order.  The same set-executor run on colour
+// classes gives multicolour Gauss-Seidel (the throughput variant; a different ordering
+// whose CPU twin for the parity tests walks the same row list sequentially).
+//
+// Two executors:
+//   * per-set launches (wide sets, e.g. the 4097-row anti-diagonals of a 4097^2 grid);
+//   * one persistent workgroup that walks all sets with a workgroup barrier between
+//     them (narrow sets: 1-D problems have n sets of ONE row; launching n kernels per
+//     sweep would be pure launch latency).
+#include <stdlib.h>
+#include <vector>
+#include "lmg_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ void gs_update_row(int i, const int *rowptr, const int *colidx,
+                                              const double *vals, double *x, const double *b)
+{
+    const int s = rowptr[i], e = rowptr[i + 1];
+    double rsum = 0.0, diag = 0.0;
+    for (int jj = s; jj < e; ++jj) {
+        const int j = colidx[jj];
+        const double v = vals[jj];
+        if (j == i) diag = v;
+        else rsum += v * x[j];
+    }
+    if (diag != 0.0) x[i] = (b[i] - rsum) / diag;
+}
+
+__global__ void __launch_bounds__(256) gs_rows_kernel(const int *rowptr, const int *colidx,
+                                                      const double *vals, double *x, const double *b,
+                                                      const int *rows, int64_t nrows)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nrows) gs_update_row(rows[k], rowptr, colidx, vals, x, b);
+}
+
+// One workgroup, all sets, all sweeps.  Global stores of set s must be visible to the
+// loads of set s+1 issued by other waves of the SAME workgroup (same CU): a
+// workgroup-scope release/acquire fence around the barrier is sufficient for that.
+constexpr int kSingleBlock = 1024;
+__global__ void __launch_bounds__(kSingleBlock) gs_single_wg_kernel(
+    const int *rowptr, const int *colidx, const double *vals, double *x, const double *b,
+    const int *set_rows, const int *set_ptr, int64_t nsets, int sweeps)
+{
+    for (int sw = 0; sw < sweeps; ++sw) {
+        for (int64_t s = 0; s < nsets; ++s) {
+            const int lo = set_ptr[s], hi = set_ptr[s + 1];
+            for (int k = lo + (int)threadIdx.x; k < hi; k += kSingleBlock)
+                gs_update_row(set_rows[k], rowptr, colidx, vals, x, b);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+}
+
+// Pattern of A^T (CSC of A) on the host: counting sort by column.
+void transpose_pattern(int64_t n, const int32_t *Ap, const int32_t *Aj, std::vector<int32_t> &Tp,
+                       std::vector<int32_t> &Tj)
+{
+    const int64_t nnz = Ap[n];
+    Tp.assign(n + 1, 0);
+    Tj.resize(nnz);
+    for (int64_t k = 0; k < nnz; ++k)
+        if (Aj[k] >= 0 && Aj[k] < n) Tp[Aj[k] + 1]++;
+    for (int64_t i = 0; i < n; ++i) Tp[i + 1] += Tp[i];
+    std::vector<int32_t> next(Tp.begin(), Tp.end() - 1);
+    for (int64_t i = 0; i < n; ++i)
+        for (int32_t k = Ap[i]; k < Ap[i + 1]; ++k) {
+            const int32_t j = Aj[k];
+            if (j >= 0 && j < n) Tj[next[j]++] = (int32_t)i;
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lmg_csr_gs_rows(const int32_t *rp, const int32_t *ci, const double *va, double *x, const double *b,
+                    const int32_t *rows, int64_t nrows, void *stream)
+{
+    if (nrows < 0 || !rp || !ci || !va || !x || !b || (nrows > 0 && !rows)) return LMG_ERR_ARG;
+    if (nrows == 0) return LMG_OK;
+    const int block = nrows >= 256 ? 256 : 64;
+    const unsigned grid = (unsigned)((nrows + block - 1) / block);
+    hipLaunchKernelGGL(gs_rows_kernel, dim3(grid), dim3(block), 0, lmg_stream(stream), rp, ci, va, x, b,
+                       rows, nrows);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_csr_gs_schedule(const int32_t *rp, const int32_t *ci, const double *va, double *x,
+                        const double *b, const int32_t *d_set_rows, const int32_t *d_set_ptr,
+                        const int32_t *h_set_ptr, int64_t nsets, int64_t max_set, int sweeps,
+                        void *stream)
+{
+    if (nsets < 0 || sweeps < 0 || !rp || !ci || !va || !x || !b) return LMG_ERR_ARG;
+    if (nsets == 0 || sweeps == 0) return LMG_OK;
+    if (!d_set_rows || !d_set_ptr || !h_set_ptr) return LMG_ERR_ARG;
+    hipStream_t st = lmg_stream(stream);
+    if (max_set <= 2 * kSingleBlock) {
+        hipLaunchKernelGGL(gs_single_wg_kernel, dim3(1), dim3(kSingleBlock), 0, st, rp, ci, va, x, b,
+                           d_set_rows, d_set_ptr, nsets, sweeps);
+        LMG_CHECK_LAUNCH();
+        return LMG_OK;
+    }
+    for (int sw = 0; sw < sweeps; ++sw)
+        for (int64_t s = 0; s < nsets; ++s) {
+            const int64_t cnt = (int64_t)h_set_ptr[s + 1] - h_set_ptr[s];
+            if (cnt <= 0) continue;
+            const int block = cnt >= 256 ? 256 : 64;
+            const unsigned grid = (unsigned)((cnt + block - 1) / block);
+            hipLaunchKernelGGL(gs_rows_kernel, dim3(grid), dim3(block), 0, st, rp, ci, va, x, b,
+                               d_set_rows + h_set_ptr[s], cnt);
+        }
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int64_t lmg_host_gs_levels(int64_t n, const int32_t *Ap, const int32_t *Aj, int32_t *level)
+{
+    if (n < 0 || !Ap || (n > 0 && !level)) return LMG_ERR_ARG;
+    if (n == 0) return 0;
+    if (Ap[n] > 0 && !Aj) return LMG_ERR_ARG;
+    std::vector<int32_t> Tp, Tj;
+    transpose_pattern(n, Ap, Aj, Tp, Tj);
+    int32_t nlev = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        int32_t lv = -1;
+        for (int32_t k = Ap[i]; k < Ap[i + 1]; ++k) {
+            const int32_t j = Aj[k];
+            if (j >= 0 && j < i && level[j] > lv) lv = level[j];
+        }
+        for (int32_t k = Tp[i]; k < Tp[i + 1]; ++k) {
+            const int32_t j = Tj[k];
+            if (j < i && level[j] > lv) lv = level[j];
+        }
+        level[i] = lv + 1;
+        if (lv + 2 > nlev) nlev = lv + 2;
+    }
+    return nlev;
+}
+
+int64_t lmg_host_greedy_colors(int64_t n, const int32_t *Ap, const int32_t *Aj, int32_t *color)
+{
+    if (n < 0 || !Ap || (n > 0 && !color)) return LMG_ERR_ARG;
+    if (n == 0) return 0;
+    if (Ap[n] > 0 && !Aj) return LMG_ERR_ARG;
+    std::vector<int32_t> Tp, Tj;
+    transpose_pattern(n, Ap, Aj, Tp, Tj);
+    std::vector<int64_t> mark;   // mark[c] == i  <=> colour c is taken by an earlier neighbour of i
+    int32_t ncol = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        for (int32_t k = Ap[i]; k < Ap[i + 1]; ++k) {
+            const int32_t j = Aj[k];
+            if (j >= 0 && j < i) mark[color[j]] = i;
+        }
+        for (int32_t k = Tp[i]; k < Tp[i + 1]; ++k) {
+            const int32_t j = Tj[k];
+            if (j < i) mark[color[j]] = i;
+        }
+        int32_t c = 0;
+        while (c < ncol && mark[c] == i) ++c;
+        if (c == ncol) {
+            mark.push_back(-1);
+            ++ncol;
+        }
+        color[i] = c;
+    }
+    return ncol;
+}
+
+}  // extern "C"

@@ -1,0 +1,258 @@
+// Galerkin product on gfx950: row-wise SpGEMM  C = A * B  (CSR x CSR -> CSR, sorted rows).
+//
+// Replaces the two csr_matmat passes behind `i.T @ A @ i` (Multigrid.py:97-98).  SpGEMM is
+// integer-heavy and HBM/latency-bound; there is nothing MFMA-shaped in it.
+//
+// One workgroup owns one row of C at a time (grid-stride over rows):
+//   expand   : thread l takes the l-th entry a_ij of the A row and streams B's row j,
+//              writing (key, a_ij*b_jk) at its slot of an LDS product list; the slot
+//              offsets come from a workgroup scan of the B row lengths, so the list is
+//              in the exact order SciPy's Gustavson loop visits the products;
+//   sort     : bitonic sort of the list in LDS by key = (column << 32 | sequence number)
+//              -- the sequence number makes the sort stable;
+//   compress : segment heads get their output slot from a scan of head flags, and each
+//              head adds its segment IN ORDER, so c_ik is the same left-to-right sum of
+//              separately rounded products that SciPy computes (bit-identical values);
+//              unlike SciPy, entries that cancel to exactly 0.0 are kept (explicit zeros).
+// The symbolic pass is the same pipeline on 32-bit keys only and returns nnz(C_i).
+// Three size classes (64-thread workgroup with 128 or 1024 slots, 256-thread workgroup
+// with 8192 slots) are chosen per launch from the largest product count of any row.
+#include "lmg_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < LMG_WAVE; off <<= 1) {
+        const int u = __shfl_up(v, off, LMG_WAVE);
+        if (lane >= off) v += u;
+    }
+    return v;
+}
+
+// Exclusive scan of one int per thread across the workgroup; *total gets the sum.
+// s_w holds BLOCK/64 + 1 ints.  Contains barriers: call from all threads.
+template <int BLOCK>
+__device__ __forceinline__ int block_excl_scan(int v, int *s_w, int *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int incl = wave_incl_scan_i(v, lane);
+    if (BLOCK == LMG_WAVE) {
+        *total = __shfl(incl, 63, LMG_WAVE);
+        return incl - v;
+    }
+    __syncthreads();                       // s_w may still be read from a previous call
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / LMG_WAVE; ++w) {
+        const int sw = s_w[w];
+        if (w < wave) woff += sw;
+        tot += sw;
+    }
+    *total = tot;
+    return woff + incl - v;
+}
+
+__device__ __forceinline__ int next_pow2(int v)
+{
+    int m = 1;
+    while (m < v) m <<= 1;
+    return m;
+}
+
+template <int BLOCK, typename KEY, bool WITH_VAL>
+__device__ __forceinline__ void bitonic_sort_lds(KEY *key, double *val, int m)
+{
+    for (int k = 2; k <= m; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (m >> 1); t += BLOCK) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int p = i | j;
+                const bool up = (i & k) == 0;
+                const KEY a = key[i], b = key[p];
+                if ((a > b) == up) {
+                    key[i] = b;
+                    key[p] = a;
+                    if (WITH_VAL) {
+                        const double va = val[i], vb = val[p];
+                        val[i] = vb;
+                        val[p] = va;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) count_products_kernel(int64_t a_rows, const int *Ap,
+                                                             const int *Aj, const int *Bp,
+                                                             int *row_products, int *max_products)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int np = 0;
+    if (i < a_rows) {
+        for (int jj = Ap[i]; jj < Ap[i + 1]; ++jj) {
+            const int j = Aj[jj];
+            np += Bp[j + 1] - Bp[j];
+        }
+        row_products[i] = np;
+    }
+    // one atomic per wave
+    int m = np;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off, LMG_WAVE));
+    if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(max_products, m);
+}
+
+template <int BLOCK, int CAP, bool NUMERIC>
+__global__ void __launch_bounds__(BLOCK) spgemm_row_kernel(
+    int64_t a_rows, const int *Ap, const int *Aj, const double *Ax, const int *Bp, const int *Bj,
+    const double *Bx, const int *row_products, int *c_rownnz, const int *Cp, int *Cj, double *Cx)
+{
+    using KEY = typename std::conditional<NUMERIC, unsigned long long, unsigned int>::type;
+    constexpr KEY kPad = ~(KEY)0;
+    __shared__ KEY s_key[CAP];
+    __shared__ double s_val[NUMERIC ? CAP : 1];
+    __shared__ int s_w[BLOCK / LMG_WAVE + 1];
+
+    for (int64_t row = blockIdx.x; row < a_rows; row += gridDim.x) {
+        const int np = row_products[row];
+        if (np == 0) {
+            if (!NUMERIC && threadIdx.x == 0) c_rownnz[row] = 0;
+            continue;
+        }
+        if (np > CAP) continue;   // rejected on the host side; never reached
+        const int a_s = Ap[row], a_e = Ap[row + 1];
+        const int m = next_pow2(np);
+        __syncthreads();          // previous row fully consumed
+        // ---- expand -----------------------------------------------------------------
+        int done = 0;
+        for (int c0 = a_s; c0 < a_e; c0 += BLOCK) {
+            const int jj = c0 + (int)threadIdx.x;
+            int bs = 0, len = 0;
+            double av = 0.0;
+            if (jj < a_e) {
+                const int j = Aj[jj];
+                bs = Bp[j];
+                len = Bp[j + 1] - bs;
+                if (NUMERIC) av = Ax[jj];
+            }
+            int chunk_total;
+            const int off = done + block_excl_scan<BLOCK>(len, s_w, &chunk_total);
+            for (int kk = 0; kk < len; ++kk) {
+                const int col = Bj[bs + kk];
+                if (NUMERIC) {
+                    s_key[off + kk] = (KEY)(((unsigned long long)(unsigned)col << 32) |
+                                            (unsigned)(off + kk));
+                    s_val[off + kk] = av * Bx[bs + kk];
+                } else {
+                    s_key[off + kk] = (KEY)(unsigned)col;
+                }
+            }
+            done += chunk_total;
+        }
+        for (int p = np + (int)threadIdx.x; p < m; p += BLOCK) s_key[p] = kPad;
+        __syncthreads();
+        // ---- sort -------------------------------------------------------------------
+        bitonic_sort_lds<BLOCK, KEY, NUMERIC>(s_key, s_val, m);
+        // ---- compress ---------------------------------------------------------------
+        int base_out = 0;
+        for (int p0 = 0; p0 < np; p0 += BLOCK) {
+            const int p = p0 + (int)threadIdx.x;
+            bool head = false;
+            unsigned col = 0;
+            if (p < np) {
+                col = NUMERIC ? (unsigned)((unsigned long long)s_key[p] >> 32) : (unsigned)s_key[p];
+                if (p == 0) head = true;
+                else {
+                    const unsigned prev = NUMERIC ? (unsigned)((unsigned long long)s_key[p - 1] >> 32)
+                                                  : (unsigned)s_key[p - 1];
+                    head = prev != col;
+                }
+            }
+            int nheads;
+            const int rank = base_out + block_excl_scan<BLOCK>(head ? 1 : 0, s_w, &nheads);
+            if (NUMERIC && head) {
+                double sum = 0.0;
+                int q = p;
+                while (q < np && (unsigned)((unsigned long long)s_key[q] >> 32) == col) {
+                    sum += s_val[q];
+                    ++q;
+                }
+                const int o = Cp[row] + rank;
+                Cj[o] = (int)col;
+                Cx[o] = sum;
+            }
+            base_out += nheads;
+        }
+        if (!NUMERIC && threadIdx.x == 0) c_rownnz[row] = base_out;
+    }
+}
+
+template <bool NUMERIC>
+int launch_rows(int64_t a_rows, const int *Ap, const int *Aj, const double *Ax, const int *Bp,
+                const int *Bj, const double *Bx, const int *row_products, int max_products,
+                int *c_rownnz, const int *Cp, int *Cj, double *Cx, hipStream_t st)
+{
+    if (a_rows == 0) return LMG_OK;
+    if (max_products > LMG_SPGEMM_MAX_ROW_PRODUCTS) return LMG_ERR_CAPACITY;
+    int64_t g = a_rows;
+    if (max_products <= 128) {
+        if (g > 256 * 32) g = 256 * 32;
+        hipLaunchKernelGGL((spgemm_row_kernel<64, 128, NUMERIC>), dim3((unsigned)g), dim3(64), 0, st,
+                           a_rows, Ap, Aj, Ax, Bp, Bj, Bx, row_products, c_rownnz, Cp, Cj, Cx);
+    } else if (max_products <= 1024) {
+        if (g > 256 * 10) g = 256 * 10;
+        hipLaunchKernelGGL((spgemm_row_kernel<64, 1024, NUMERIC>), dim3((unsigned)g), dim3(64), 0, st,
+                           a_rows, Ap, Aj, Ax, Bp, Bj, Bx, row_products, c_rownnz, Cp, Cj, Cx);
+    } else {
+        if (g > 256 * 2) g = 256 * 2;
+        hipLaunchKernelGGL((spgemm_row_kernel<256, 8192, NUMERIC>), dim3((unsigned)g), dim3(256), 0, st,
+                           a_rows, Ap, Aj, Ax, Bp, Bj, Bx, row_products, c_rownnz, Cp, Cj, Cx);
+    }
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lmg_spgemm_count(int64_t a_rows, const int32_t *Ap, const int32_t *Aj, const int32_t *Bp,
+                     int32_t *row_products, int32_t *max_products, void *stream)
+{
+    if (a_rows < 0 || !Ap || !Bp || !row_products || !max_products) return LMG_ERR_ARG;
+    hipStream_t st = lmg_stream(stream);
+    if (hipMemsetAsync(max_products, 0, sizeof(int32_t), st) != hipSuccess) return LMG_ERR_LAUNCH;
+    if (a_rows == 0) return LMG_OK;
+    const unsigned grid = (unsigned)((a_rows + 255) / 256);
+    hipLaunchKernelGGL(count_products_kernel, dim3(grid), dim3(256), 0, st, a_rows, Ap, Aj, Bp,
+                       row_products, max_products);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_spgemm_symbolic(int64_t a_rows, const int32_t *Ap, const int32_t *Aj, const int32_t *Bp,
+                        const int32_t *Bj, const int32_t *row_products, int32_t max_products,
+                        int32_t *c_rownnz, void *stream)
+{
+    if (a_rows < 0 || !Ap || !Bp || !row_products || !c_rownnz) return LMG_ERR_ARG;
+    return launch_rows<false>(a_rows, Ap, Aj, nullptr, Bp, Bj, nullptr, row_products, max_products,
+                              c_rownnz, nullptr, nullptr, nullptr, lmg_stream(stream));
+}
+
+int lmg_spgemm_numeric(int64_t a_rows, const int32_t *Ap, const int32_t *Aj, const double *Ax,
+                       const int32_t *Bp, const int32_t *Bj, const double *Bx,
+                       const int32_t *row_products, int32_t max_products, const int32_t *Cp,
+                       int32_t *Cj, double *Cx, void *stream)
+{
+    if (a_rows < 0 || !Ap || !Bp || !row_products || !Cp) return LMG_ERR_ARG;
+    return launch_rows<true>(a_rows, Ap, Aj, Ax, Bp, Bj, Bx, row_products, max_products, nullptr,
+                             Cp, Cj, Cx, lmg_stream(stream));
+}
+
+}  // extern "C"

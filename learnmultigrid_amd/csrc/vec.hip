@@ -1,0 +1,351 @@
+// Vector kernels, halo pack/unpack, dense coarse-operator GEMV, scan, hipGraph helpers,
+// and the small management entry points of the C ABI.
+#include <string.h>
+#include "lmg_common.hpp"
+
+int lmg_sweep_tune_set(int rpt);
+int lmg_sweep_tune_get(void);
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxGrid = 256 * 8;   // 256 CUs x 8 resident workgroups: grid-stride beyond
+
+inline unsigned grid_for(int64_t n, int per_block)
+{
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g > kMaxGrid) g = kMaxGrid;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// y = alpha*x + beta*y, two elements (16 bytes) per lane per step.
+__global__ void __launch_bounds__(kBlock) axpby_kernel(int64_t n, double alpha, const double *x,
+                                                       double beta, double *y)
+{
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    double2 *y2 = reinterpret_cast<double2 *>(y);
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+        const double2 xv = x2[i];
+        double2 yv;
+        if (beta == 0.0) {
+            yv.x = alpha * xv.x;
+            yv.y = alpha * xv.y;
+        } else {
+            yv = y2[i];
+            yv.x = alpha * xv.x + beta * yv.x;
+            yv.y = alpha * xv.y + beta * yv.y;
+        }
+        y2[i] = yv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        y[i] = (beta == 0.0) ? alpha * x[i] : alpha * x[i] + beta * y[i];
+    }
+}
+
+// fixed geometry (1024 partials) so the result does not depend on tuning knobs
+__global__ void __launch_bounds__(kBlock) dot_kernel(int64_t n, const double *x, const double *y,
+                                                     double *partial)
+{
+    __shared__ double s_red[kBlock / LMG_WAVE];
+    double v = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) v += x[i] * y[i];
+    const double tot = lmg_block_sum<kBlock>(v, s_red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(1024) dot_final_kernel(const double *partial, int count, double *out)
+{
+    __shared__ double s_red[1024 / LMG_WAVE];
+    double v = (int)threadIdx.x < count ? partial[threadIdx.x] : 0.0;
+    const double tot = lmg_block_sum<1024>(v, s_red);
+    if (threadIdx.x == 0) out[0] = tot;
+}
+
+__global__ void __launch_bounds__(kBlock) gather_kernel(int64_t n, const int *idx, const double *x,
+                                                        double *buf)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) buf[i] = x[idx[i]];
+}
+
+__global__ void __launch_bounds__(kBlock) scatter_kernel(int64_t n, const int *idx, const double *buf,
+                                                         double *x)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) x[idx[i]] = buf[i];
+}
+
+// Dense y = M x, one wave per row, 16 bytes per lane per step, fixed summation order.
+// HBM-bound: 8*n*m bytes of M per call.
+__global__ void __launch_bounds__(kBlock) dense_gemv_kernel(int64_t n, int64_t m, const double *M,
+                                                            const double *x, double *y)
+{
+    const int lane = threadIdx.x & (LMG_WAVE - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LMG_WAVE;
+    const int64_t nwaves = (int64_t)gridDim.x * kBlock / LMG_WAVE;
+    const bool vec_ok = (m % 2 == 0);
+    for (int64_t row = wave; row < n; row += nwaves) {
+        const double *Mr = M + row * m;
+        double s = 0.0;
+        if (vec_ok) {
+            const double2 *M2 = reinterpret_cast<const double2 *>(Mr);
+            const double2 *x2 = reinterpret_cast<const double2 *>(x);
+            for (int64_t j = lane; j < m / 2; j += LMG_WAVE) {
+                const double2 mv = M2[j], xv = x2[j];
+                s += mv.x * xv.x;
+                s += mv.y * xv.y;
+            }
+        } else {
+            for (int64_t j = lane; j < m; j += LMG_WAVE) s += Mr[j] * x[j];
+        }
+        s = lmg_wave_sum(s);
+        if (lane == 0) y[row] = s;
+    }
+}
+
+// ---- exclusive scan (int32): per-block scan + block sums + add-back -------------------
+constexpr int kScanBlock = 1024;
+constexpr int kScanItems = 4;
+constexpr int kScanTile = kScanBlock * kScanItems;
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < LMG_WAVE; off <<= 1) {
+        const int u = __shfl_up(v, off, LMG_WAVE);
+        if (lane >= off) v += u;
+    }
+    return v;
+}
+
+// scans one tile; out[i+1] receives the inclusive value (caller pre-writes out[0] = 0)
+__global__ void __launch_bounds__(kScanBlock) scan_tile_kernel(int64_t n, const int *in, int *out,
+                                                               int *block_sums)
+{
+    __shared__ int s_wave[kScanBlock / LMG_WAVE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)t * kScanItems;
+    int v[kScanItems];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        sum += v[k];
+    }
+    const int incl = wave_incl_scan(sum, lane);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        const int w = (lane < kScanBlock / LMG_WAVE) ? s_wave[lane] : 0;
+        const int wi = wave_incl_scan(w, lane);
+        if (lane < kScanBlock / LMG_WAVE) s_wave[lane] = wi - w;   // exclusive wave offsets
+        if (lane == kScanBlock / LMG_WAVE - 1 && block_sums) block_sums[blockIdx.x] = wi;
+    }
+    __syncthreads();
+    int run = s_wave[wave] + incl - sum;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        run += v[k];
+        if (base + k < n) out[base + k + 1] = run;
+    }
+    if (blockIdx.x == 0 && t == 0) out[0] = 0;
+}
+
+__global__ void __launch_bounds__(kScanBlock) scan_add_kernel(int64_t n, int *out, const int *block_offs)
+{
+    const int off = block_offs[blockIdx.x];
+    if (off == 0) return;
+    const int64_t base = (int64_t)blockIdx.x * kScanTile;
+    for (int i = threadIdx.x; i < kScanTile; i += kScanBlock)
+        if (base + i < n) out[base + i + 1] += off;
+}
+
+int scan_rec(int64_t n, const int *in, int *out, int *scratch, hipStream_t st)
+{
+    const int64_t blocks = (n + kScanTile - 1) / kScanTile;
+    if (blocks <= 1) {
+        hipLaunchKernelGGL(scan_tile_kernel, dim3(1), dim3(kScanBlock), 0, st, n, in, out, (int *)nullptr);
+        LMG_CHECK_LAUNCH();
+        return LMG_OK;
+    }
+    int *sums = scratch;                 // blocks entries
+    int *offs = scratch + blocks;        // blocks + 1 entries (exclusive scan of sums)
+    int *rest = offs + blocks + 1;
+    hipLaunchKernelGGL(scan_tile_kernel, dim3((unsigned)blocks), dim3(kScanBlock), 0, st, n, in, out, sums);
+    LMG_CHECK_LAUNCH();
+    int rc = scan_rec(blocks, sums, offs, rest, st);
+    if (rc != LMG_OK) return rc;
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)blocks), dim3(kScanBlock), 0, st, n, out, offs);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lmg_version(void) { return LMG_VERSION; }
+
+const char *lmg_status_string(int s)
+{
+    switch (s) {
+    case LMG_OK: return "ok";
+    case LMG_ERR_ARG: return "invalid argument";
+    case LMG_ERR_ALIGN: return "array base not 16-byte aligned";
+    case LMG_ERR_LAUNCH: return "HIP launch/runtime error";
+    case LMG_ERR_CAPACITY: return "row exceeds kernel capacity";
+    case LMG_ERR_NODEVICE: return "no HIP device";
+    default: return "unknown status";
+    }
+}
+
+int lmg_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return LMG_ERR_NODEVICE;
+    return c;
+}
+
+int lmg_tune_set(const char *key, int value)
+{
+    if (!key) return LMG_ERR_ARG;
+    if (strcmp(key, "sweep_rpt") == 0) return lmg_sweep_tune_set(value);
+    return LMG_ERR_ARG;
+}
+
+int lmg_tune_get(const char *key)
+{
+    if (!key) return LMG_ERR_ARG;
+    if (strcmp(key, "sweep_rpt") == 0) return lmg_sweep_tune_get();
+    return LMG_ERR_ARG;
+}
+
+int lmg_axpby(int64_t n, double alpha, const double *x, double beta, double *y, void *stream)
+{
+    if (n < 0 || (n > 0 && (!x || !y))) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    if (!lmg_aligned16(x) || !lmg_aligned16(y)) return LMG_ERR_ALIGN;
+    hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, kBlock * 2)), dim3(kBlock), 0, lmg_stream(stream),
+                       n, alpha, x, beta, y);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_copy(int64_t n, const double *src, double *dst, void *stream)
+{
+    if (n < 0 || (n > 0 && (!src || !dst))) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    if (hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice,
+                       lmg_stream(stream)) != hipSuccess)
+        return LMG_ERR_LAUNCH;
+    return LMG_OK;
+}
+
+int lmg_zero(int64_t n, double *x, void *stream)
+{
+    if (n < 0 || (n > 0 && !x)) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    if (hipMemsetAsync(x, 0, (size_t)n * sizeof(double), lmg_stream(stream)) != hipSuccess)
+        return LMG_ERR_LAUNCH;
+    return LMG_OK;
+}
+
+int lmg_dot(int64_t n, const double *x, const double *y, double *partials, double *out, void *stream)
+{
+    if (n < 0 || !partials || !out || (n > 0 && (!x || !y))) return LMG_ERR_ARG;
+    const unsigned grid = 1024;
+    hipLaunchKernelGGL(dot_kernel, dim3(grid), dim3(kBlock), 0, lmg_stream(stream), n, x, y, partials);
+    LMG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(1024), 0, lmg_stream(stream), partials, (int)grid, out);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_gather(int64_t n, const int32_t *idx, const double *x, double *buf, void *stream)
+{
+    if (n < 0 || (n > 0 && (!idx || !x || !buf))) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    hipLaunchKernelGGL(gather_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, lmg_stream(stream), n, idx, x, buf);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_scatter(int64_t n, const int32_t *idx, const double *buf, double *x, void *stream)
+{
+    if (n < 0 || (n > 0 && (!idx || !x || !buf))) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    hipLaunchKernelGGL(scatter_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, lmg_stream(stream), n, idx, buf, x);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_dense_gemv(int64_t n, int64_t m, const double *M, const double *x, double *y, void *stream)
+{
+    if (n < 0 || m < 0 || (n > 0 && !y) || (n > 0 && m > 0 && (!M || !x))) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    if (!lmg_aligned16(M) || !lmg_aligned16(x)) return LMG_ERR_ALIGN;
+    hipLaunchKernelGGL(dense_gemv_kernel, dim3(grid_for(n, kBlock / LMG_WAVE)), dim3(kBlock), 0,
+                       lmg_stream(stream), n, m, M, x, y);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int64_t lmg_scan_scratch_count(int64_t n)
+{
+    int64_t total = 0;
+    int64_t blocks = (n + kScanTile - 1) / kScanTile;
+    while (blocks > 1) {
+        total += 2 * blocks + 1;
+        blocks = (blocks + kScanTile - 1) / kScanTile;
+    }
+    return total + 16;
+}
+
+int lmg_exclusive_scan_i32(int64_t n, const int32_t *in, int32_t *out, int32_t *scratch, void *stream)
+{
+    if (n < 0 || !out || (n > 0 && !in)) return LMG_ERR_ARG;
+    if (n > kScanTile && !scratch) return LMG_ERR_ARG;
+    return scan_rec(n, in, out, scratch, lmg_stream(stream));
+}
+
+int lmg_graph_begin(void *stream)
+{
+    if (hipStreamBeginCapture(lmg_stream(stream), hipStreamCaptureModeThreadLocal) != hipSuccess)
+        return LMG_ERR_LAUNCH;
+    return LMG_OK;
+}
+
+int lmg_graph_end(void *stream, void **exec_out)
+{
+    if (!exec_out) return LMG_ERR_ARG;
+    hipGraph_t g = nullptr;
+    if (hipStreamEndCapture(lmg_stream(stream), &g) != hipSuccess || !g) return LMG_ERR_LAUNCH;
+    hipGraphExec_t ex = nullptr;
+    hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return LMG_ERR_LAUNCH;
+    *exec_out = ex;
+    return LMG_OK;
+}
+
+int lmg_graph_launch(void *exec, void *stream)
+{
+    if (!exec) return LMG_ERR_ARG;
+    if (hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(exec), lmg_stream(stream)) != hipSuccess)
+        return LMG_ERR_LAUNCH;
+    return LMG_OK;
+}
+
+int lmg_graph_destroy(void *exec)
+{
+    if (!exec) return LMG_OK;
+    (void)hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(exec));
+    return LMG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,323 @@
+"""Torch-facing wrappers of the C ABI (include/lmg.h) and their registration as
+PyTorch custom ops (`torch.ops.lmg.*`).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every
+arithmetic step is a hand-written gfx950 kernel reached through ctypes.  The same
+Python callables back the `torch.ops.lmg.*` ops and the solver's internal calls.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+F64 = torch.float64
+I32 = torch.int32
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _vec_ok(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if t.dtype != F64 or not t.is_contiguous() or not t.is_cuda:
+            raise TypeError("expected contiguous float64 device tensors, got %s %s contiguous=%s"
+                            % (t.dtype, t.device, t.is_contiguous()))
+
+
+class DeviceCSR:
+    """CSR matrix resident in HBM: int32 rowptr[n+1], int32 colidx[nnz], fp64 vals[nnz]."""
+
+    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz")
+
+    def __init__(self, rowptr, colidx, vals, shape):
+        if rowptr.dtype != I32 or colidx.dtype != I32 or vals.dtype != F64:
+            raise TypeError("DeviceCSR wants int32 indices and float64 values")
+        if rowptr.numel() != shape[0] + 1 or colidx.numel() != vals.numel():
+            raise ValueError("inconsistent CSR arrays")
+        self.rowptr, self.colidx, self.vals = rowptr.contiguous(), colidx.contiguous(), vals.contiguous()
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.nnz = int(vals.numel())
+
+    @classmethod
+    def from_scipy(cls, A, device, canonical=True):
+        """Any scipy.sparse matrix / ndarray -> sorted, duplicate-free CSR on `device`
+        (the form pyamg hands its kernel after the CSC->CSR conversion, Multigrid.py:88)."""
+        import scipy.sparse as sp
+        A = sp.csr_matrix(A, dtype=np.float64)
+        if canonical and not A.has_canonical_format:
+            A = A.copy()
+            A.sum_duplicates()
+        if A.nnz >= 2 ** 31 - 8192 or max(A.shape) >= 2 ** 31 - 1:
+            raise ValueError("matrix too large for int32 indices")
+        return cls(torch.from_numpy(A.indptr.astype(np.int32)).to(device),
+                   torch.from_numpy(A.indices.astype(np.int32)).to(device),
+                   torch.from_numpy(np.ascontiguousarray(A.data)).to(device), A.shape)
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.vals.cpu().numpy(), self.colidx.cpu().numpy(),
+                              self.rowptr.cpu().numpy()), shape=self.shape)
+
+    @property
+    def device(self):
+        return self.vals.device
+
+    def bytes(self):
+        return 12 * self.nnz + 4 * (self.shape[0] + 1)
+
+
+def partials_count(n):
+    return int(_lib.lib().lmg_partials_count(int(n)))
+
+
+def tune_set(key, value):
+    check(_lib.lib().lmg_tune_set(key.encode(), int(value)), "lmg_tune_set")
+
+
+def tune_get(key):
+    return check(_lib.lib().lmg_tune_get(key.encode()), "lmg_tune_get")
+
+
+# ---- sweeps ------------------------------------------------------------------------
+def csr_residual_norm2(A, x, b, r, partials, norm2):
+    """r = b - A x (r may be None), norm2[0] = sum r_i^2 (partials/norm2 may both be None)."""
+    _vec_ok(x, b, r, partials, norm2)
+    check(_lib.lib().lmg_csr_residual_norm2(A.shape[0], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.vals),
+                                            _p(x), _p(b), _p(r), _p(partials), _p(norm2), _s()),
+          "lmg_csr_residual_norm2")
+
+
+def csr_jacobi(A, x_in, b, omega, x_out):
+    _vec_ok(x_in, b, x_out)
+    check(_lib.lib().lmg_csr_jacobi(A.shape[0], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.vals),
+                                    _p(x_in), _p(b), float(omega), _p(x_out), _s()), "lmg_csr_jacobi")
+
+
+def csr_spmv(A, x, y, alpha=1.0, beta=0.0):
+    _vec_ok(x, y)
+    if x.numel() != A.shape[1] or y.numel() != A.shape[0]:
+        raise ValueError("spmv shape mismatch: A %s, x %d, y %d" % (A.shape, x.numel(), y.numel()))
+    check(_lib.lib().lmg_csr_spmv(A.shape[0], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.vals),
+                                  _p(x), _p(y), float(alpha), float(beta), _s()), "lmg_csr_spmv")
+
+
+# ---- Gauss-Seidel ---------------------------------------------------------------------
+class GSSchedule:
+    """Ordered independent sets of rows (level schedule or colour classes)."""
+
+    __slots__ = ("kind", "d_rows", "d_ptr", "h_ptr", "nsets", "max_set")
+
+    def __init__(self, kind, order, ptr, device):
+        self.kind = kind
+        self.h_ptr = np.ascontiguousarray(ptr, dtype=np.int32)
+        self.d_rows = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int32)).to(device)
+        self.d_ptr = torch.from_numpy(self.h_ptr).to(device)
+        self.nsets = int(self.h_ptr.size - 1)
+        self.max_set = int(np.diff(self.h_ptr).max()) if self.nsets else 0
+
+
+def gs_schedule_from_labels(kind, labels, nsets, device):
+    order = np.argsort(labels, kind="stable").astype(np.int32)      # ascending row inside a set
+    counts = np.bincount(labels, minlength=int(nsets))
+    ptr = np.zeros(int(nsets) + 1, dtype=np.int32)
+    np.cumsum(counts, out=ptr[1:])
+    return GSSchedule(kind, order, ptr, device)
+
+
+def build_gs_schedule(A_scipy_csr, kind, device):
+    """kind = "lexicographic" (level schedule: exact forward sweep) | "multicolor"."""
+    A = A_scipy_csr
+    n = A.shape[0]
+    rp = np.ascontiguousarray(A.indptr, dtype=np.int32)
+    ci = np.ascontiguousarray(A.indices, dtype=np.int32)
+    lab = np.empty(n, dtype=np.int32)
+    L = _lib.lib()
+    fn = {"lexicographic": L.lmg_host_gs_levels, "multicolor": L.lmg_host_greedy_colors}.get(kind)
+    if fn is None:
+        raise ValueError("unknown Gauss-Seidel ordering %r" % (kind,))
+    nsets = check(fn(n, rp.ctypes.data, ci.ctypes.data, lab.ctypes.data), "gs schedule")
+    return gs_schedule_from_labels(kind, lab, nsets, device)
+
+
+def csr_gs_rows(A, x, b, rows):
+    _vec_ok(x, b)
+    check(_lib.lib().lmg_csr_gs_rows(_p(A.rowptr), _p(A.colidx), _p(A.vals), _p(x), _p(b), _p(rows),
+                                     rows.numel(), _s()), "lmg_csr_gs_rows")
+
+
+def csr_gs_schedule(A, x, b, sched, sweeps=1):
+    _vec_ok(x, b)
+    check(_lib.lib().lmg_csr_gs_schedule(_p(A.rowptr), _p(A.colidx), _p(A.vals), _p(x), _p(b),
+                                         _p(sched.d_rows), _p(sched.d_ptr), sched.h_ptr.ctypes.data,
+                                         sched.nsets, sched.max_set, int(sweeps), _s()),
+          "lmg_csr_gs_schedule")
+
+
+# ---- vectors ------------------------------------------------------------------------------
+def axpby(alpha, x, beta, y):
+    _vec_ok(x, y)
+    check(_lib.lib().lmg_axpby(y.numel(), float(alpha), _p(x), float(beta), _p(y), _s()), "lmg_axpby")
+
+
+def copy(src, dst):
+    _vec_ok(src, dst)
+    check(_lib.lib().lmg_copy(dst.numel(), _p(src), _p(dst), _s()), "lmg_copy")
+
+
+def zero(x):
+    _vec_ok(x)
+    check(_lib.lib().lmg_zero(x.numel(), _p(x), _s()), "lmg_zero")
+
+
+def dot(x, y, partials, out):
+    _vec_ok(x, y, partials, out)
+    check(_lib.lib().lmg_dot(x.numel(), _p(x), _p(y), _p(partials), _p(out), _s()), "lmg_dot")
+
+
+def gather(idx, x, buf):
+    check(_lib.lib().lmg_gather(idx.numel(), _p(idx), _p(x), _p(buf), _s()), "lmg_gather")
+
+
+def scatter(idx, buf, x):
+    check(_lib.lib().lmg_scatter(idx.numel(), _p(idx), _p(buf), _p(x), _s()), "lmg_scatter")
+
+
+def dense_gemv(M, x, y):
+    _vec_ok(M, x, y)
+    check(_lib.lib().lmg_dense_gemv(M.shape[0], M.shape[1], _p(M), _p(x), _p(y), _s()), "lmg_dense_gemv")
+
+
+# ---- SpGEMM ---------------------------------------------------------------------------------
+def exclusive_scan_i32(inp, out):
+    n = inp.numel()
+    sc = torch.empty(int(_lib.lib().lmg_scan_scratch_count(n)), dtype=I32, device=inp.device)
+    check(_lib.lib().lmg_exclusive_scan_i32(n, _p(inp), _p(out), _p(sc), _s()), "lmg_exclusive_scan_i32")
+
+
+class SpGEMMPlan:
+    """Symbolic result of C = A*B (pattern of C + per-row product counts); `numeric`
+    can be re-run when only the values of A or B changed (Galerkin rebuild)."""
+
+    def __init__(self, A, B):
+        if A.shape[1] != B.shape[0]:
+            raise ValueError("spgemm shape mismatch %s x %s" % (A.shape, B.shape))
+        dev = A.device
+        n = A.shape[0]
+        L = _lib.lib()
+        self.shape = (A.shape[0], B.shape[1])
+        self.row_products = torch.empty(max(n, 1), dtype=I32, device=dev)
+        mx = torch.zeros(1, dtype=I32, device=dev)
+        check(L.lmg_spgemm_count(n, _p(A.rowptr), _p(A.colidx), _p(B.rowptr), _p(self.row_products),
+                                 _p(mx), _s()), "lmg_spgemm_count")
+        self.max_products = int(mx.item())
+        rownnz = torch.empty(max(n, 1), dtype=I32, device=dev)
+        check(L.lmg_spgemm_symbolic(n, _p(A.rowptr), _p(A.colidx), _p(B.rowptr), _p(B.colidx),
+                                    _p(self.row_products), self.max_products, _p(rownnz), _s()),
+              "lmg_spgemm_symbolic")
+        self.c_rowptr = torch.empty(n + 1, dtype=I32, device=dev)
+        exclusive_scan_i32(rownnz[:n], self.c_rowptr)
+        self.c_nnz = int(self.c_rowptr[-1].item())
+
+    def numeric(self, A, B, out=None):
+        dev = A.device
+        if out is None:
+            out = DeviceCSR(self.c_rowptr, torch.empty(self.c_nnz, dtype=I32, device=dev),
+                            torch.empty(self.c_nnz, dtype=F64, device=dev), self.shape)
+        check(_lib.lib().lmg_spgemm_numeric(A.shape[0], _p(A.rowptr), _p(A.colidx), _p(A.vals),
+                                            _p(B.rowptr), _p(B.colidx), _p(B.vals),
+                                            _p(self.row_products), self.max_products,
+                                            _p(out.rowptr), _p(out.colidx), _p(out.vals), _s()),
+              "lmg_spgemm_numeric")
+        return out
+
+
+def spgemm(A, B):
+    return SpGEMMPlan(A, B).numeric(A, B)
+
+
+# ---- hipGraph ---------------------------------------------------------------------------------
+class CapturedGraph:
+    """A launch sequence captured on the current stream (lmg_graph_*), replayable."""
+
+    def __init__(self):
+        self._exec = ctypes.c_void_p(None)
+
+    def __enter__(self):
+        check(_lib.lib().lmg_graph_begin(_s()), "lmg_graph_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rc = _lib.lib().lmg_graph_end(_s(), ctypes.byref(self._exec))
+        if et is None:
+            check(rc, "lmg_graph_end")
+        return False
+
+    def launch(self):
+        check(_lib.lib().lmg_graph_launch(self._exec, _s()), "lmg_graph_launch")
+
+    def __del__(self):
+        try:
+            if self._exec:
+                _lib.lib().lmg_graph_destroy(self._exec)
+        except Exception:
+            pass
+
+
+# ---- torch.ops.lmg.* registration ------------------------------------------------------------
+_registered = False
+
+
+def register_torch_ops():
+    """Expose the kernels as PyTorch custom ops taking ROCm tensors, e.g.
+    torch.ops.lmg.csr_jacobi(rowptr, colidx, vals, x, b, omega) -> x_new."""
+    global _registered
+    if _registered:
+        return
+    lib = torch.library.Library("lmg", "DEF")
+    lib.define("csr_residual(Tensor rowptr, Tensor colidx, Tensor vals, Tensor x, Tensor b) -> (Tensor, Tensor)")
+    lib.define("csr_jacobi(Tensor rowptr, Tensor colidx, Tensor vals, Tensor x, Tensor b, float omega) -> Tensor")
+    lib.define("csr_spmv(Tensor rowptr, Tensor colidx, Tensor vals, int ncols, Tensor x) -> Tensor")
+    lib.define("csr_gs_rows_(Tensor rowptr, Tensor colidx, Tensor vals, Tensor(a!) x, Tensor b, Tensor rows) -> ()")
+
+    def _csr(rowptr, colidx, vals, ncols):
+        return DeviceCSR(rowptr, colidx, vals, (rowptr.numel() - 1, ncols))
+
+    def op_residual(rowptr, colidx, vals, x, b):
+        A = _csr(rowptr, colidx, vals, x.numel())
+        r = torch.empty_like(x)
+        part = torch.empty(partials_count(A.shape[0]), dtype=F64, device=x.device)
+        n2 = torch.empty(1, dtype=F64, device=x.device)
+        csr_residual_norm2(A, x, b, r, part, n2)
+        return r, n2
+
+    def op_jacobi(rowptr, colidx, vals, x, b, omega):
+        A = _csr(rowptr, colidx, vals, x.numel())
+        out = torch.empty_like(x)
+        csr_jacobi(A, x, b, omega, out)
+        return out
+
+    def op_spmv(rowptr, colidx, vals, ncols, x):
+        A = _csr(rowptr, colidx, vals, ncols)
+        y = torch.empty(A.shape[0], dtype=F64, device=x.device)
+        csr_spmv(A, x, y, 1.0, 0.0)
+        return y
+
+    def op_gs_rows_(rowptr, colidx, vals, x, b, rows):
+        csr_gs_rows(_csr(rowptr, colidx, vals, x.numel()), x, b, rows)
+
+    lib.impl("csr_residual", op_residual, "CUDA")
+    lib.impl("csr_jacobi", op_jacobi, "CUDA")
+    lib.impl("csr_spmv", op_spmv, "CUDA")
+    lib.impl("csr_gs_rows_", op_gs_rows_, "CUDA")
+    register_torch_ops._lib = lib        # keep alive
+    _registered = True

@@ -1,0 +1,90 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds for gfx950, loads,
+and exports exactly the symbols include/lmg.h declares; the product never imports the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from learnmultigrid_amd import _lib
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "lmg.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lmg_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    _lib.build()
+    return ctypes.CDLL(_lib.LIB_PATH)
+
+
+def test_header_and_binding_table_agree():
+    assert header_symbols() == sorted(_lib.SIGNATURES)
+
+
+def test_library_exports_every_declared_symbol(built):
+    for name in header_symbols():
+        assert hasattr(built, name), name
+
+
+def test_library_loads_and_answers_without_a_gpu(built):
+    L = _lib.lib()
+    assert L.lmg_version() == 100
+    assert L.lmg_status_string(0) == b"ok"
+    assert L.lmg_status_string(-4) == b"row exceeds kernel capacity"
+    assert L.lmg_partials_count(16785409) >= 16785409 // 256
+    assert L.lmg_scan_scratch_count(10) >= 0
+    assert L.lmg_tune_set(b"sweep_rpt", 3) < 0          # invalid values are rejected
+    assert L.lmg_tune_set(b"nonsense", 1) < 0
+    assert L.lmg_tune_get(b"sweep_rpt") in (1, 2, 4)
+
+
+def test_host_schedule_helpers():
+    import numpy as np
+    from learnmultigrid_amd import problems as P
+    A, _ = P.poisson_2d_structured(8)               # 9x9 grid, boundary rows are identity rows
+    rp, ci = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    n = A.shape[0]
+    lev = np.empty(n, dtype=np.int32)
+    L = _lib.lib()
+    nlev = L.lmg_host_gs_levels(n, rp.ctypes.data, ci.ctypes.data, lev.ctypes.data)
+    i, j = np.arange(n) % 9, np.arange(n) // 9
+    # interior nodes form anti-diagonals; identity boundary rows still wait for the interior
+    # neighbours that READ them (anti-dependency through A^T)
+    assert nlev == lev.max() + 1
+    inter = (i > 0) & (i < 8) & (j > 0) & (j < 8)
+    d = lev[inter] - (i[inter] + j[inter])
+    assert np.all(d == d[0])
+    col = np.empty(n, dtype=np.int32)
+    ncol = L.lmg_host_greedy_colors(n, rp.ctypes.data, ci.ctypes.data, col.ctypes.data)
+    # identity boundary rows all take colour 0, so greedy needs a third colour next to them
+    assert 2 <= ncol <= 4 and col.max() == ncol - 1
+    S = (abs(A) + abs(A.T)).tocoo()
+    off = S.row != S.col
+    assert np.all(col[S.row[off]] != col[S.col[off]])
+    # 1-D chain: n levels of one row
+    A1, _ = P.poisson_1d_fd(16)
+    rp, ci = A1.indptr.astype(np.int32), A1.indices.astype(np.int32)
+    lev = np.empty(17, dtype=np.int32)
+    assert L.lmg_host_gs_levels(17, rp.ctypes.data, ci.ctypes.data, lev.ctypes.data) >= 15
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "learnmultigrid_amd")
+    for dirpath, _d, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "lmg_oracle" not in src, f
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.LmgError):
+        _lib.lib()

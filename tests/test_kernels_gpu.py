@@ -1,0 +1,355 @@
+"""Parity of every HIP kernel behind the C ABI against the CPU oracle (-m gpu).
+
+Bars: bit-exact for SpMV / residual / Jacobi / Gauss-Seidel / SpGEMM values and all
+integer outputs (same accumulation order, no FMA contraction on either side);
+1e-13 relative for the reductions whose summation tree differs (norms, dot, GEMV).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from learnmultigrid_amd import ops, problems as P   # noqa: E402
+from oracle import kernels as K                     # noqa: E402  (checker only)
+
+DEV = "cuda:0"
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def ragged_matrix(n, seed, long_row=None, empty_every=7, long_len=5000):
+    """Random nonsymmetric CSR with empty rows, missing diagonals and (optionally) one
+    row far longer than any LDS tile."""
+    rng = np.random.default_rng(seed)
+    A = sp.random(n, n, density=min(1.0, 6.0 / n), random_state=seed, format="lil")
+    A.setdiag(rng.uniform(2, 4, n))
+    for r in range(3, n, empty_every):
+        A[r, :] = 0
+    if long_row is not None:
+        cols = rng.choice(n, size=min(n, long_len), replace=False)
+        A[long_row, cols] = rng.standard_normal(cols.size)
+    A = sp.csr_matrix(A)
+    A.eliminate_zeros()
+    return K.as_csr(A)
+
+
+import functools
+
+
+@functools.lru_cache(maxsize=None)
+def case(name):
+    """Matrices are built lazily so that collecting this module on a CPU-only run is free."""
+    if name == "poisson1d_1025":
+        return K.as_csr(P.poisson_1d_fd(1024)[0])
+    if name == "poisson2d_65":
+        return K.as_csr(P.poisson_2d_structured(64)[0])
+    if name == "poisson2d_513":
+        return K.as_csr(P.poisson_2d_structured(512)[0])
+    if name == "ragged_1000":
+        return ragged_matrix(1000, 1)
+    if name == "ragged_longrow_6007":
+        return ragged_matrix(6007, 2, long_row=4001)
+    if name == "tiny_3":
+        return K.as_csr(sp.csr_matrix(np.array([[30., 1, 15], [28, 60, 3], [100, 19, 150]])))
+    if name == "prolong_65":
+        return K.as_csr(P.tensor_interpolator_2d(65))
+    if name == "restrict_65":
+        return K.as_csr(P.tensor_interpolator_2d(65).T.tocsr())
+    if name == "l2like_restrict":
+        return K.as_csr(sp.kron(P.pseudo_l2_interpolator_1d(65),
+                                P.pseudo_l2_interpolator_1d(65)).T.tocsr())
+    raise KeyError(name)
+
+
+SQUARE = ["poisson1d_1025", "poisson2d_65", "poisson2d_513", "ragged_1000", "ragged_longrow_6007",
+          "tiny_3"]
+ALL = SQUARE + ["prolong_65", "restrict_65", "l2like_restrict"]
+
+
+@pytest.fixture(params=[1, 2, 4], ids=lambda r: "rpt%d" % r)
+def rpt(request):
+    ops.tune_set("sweep_rpt", request.param)
+    yield request.param
+    ops.tune_set("sweep_rpt", 1)
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_spmv_bit_exact(name, rpt):
+    A = case(name)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(A.shape[1])
+    y0 = rng.standard_normal(A.shape[0])
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (-0.5, 2.0)):
+        y = dev(y0.copy())
+        ops.csr_spmv(dA, dev(x), y, alpha, beta)
+        want = K.spmv(A, x, y0, alpha, beta)
+        assert np.array_equal(y.cpu().numpy(), want), (name, alpha, beta)
+    y = dev(np.zeros(A.shape[0]))
+    ops.csr_spmv(dA, dev(x), y, 1.0, 0.0)
+    assert np.array_equal(y.cpu().numpy(), A @ x)              # SciPy itself
+
+
+@pytest.mark.parametrize("name", SQUARE)
+def test_residual_and_jacobi_bit_exact(name, rpt):
+    A = case(name)
+    rng = np.random.default_rng(6)
+    n = A.shape[0]
+    x, b = rng.standard_normal(n), rng.standard_normal(n)
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    dx, db = dev(x), dev(b)
+    r = torch.empty(n, dtype=torch.float64, device=DEV)
+    part = torch.empty(ops.partials_count(n), dtype=torch.float64, device=DEV)
+    n2 = torch.zeros(1, dtype=torch.float64, device=DEV)
+    ops.csr_residual_norm2(dA, dx, db, r, part, n2)
+    want_r, want_n2 = K.residual(A, x, b)
+    assert np.array_equal(r.cpu().numpy(), want_r)
+    assert abs(n2.item() - want_n2) <= 1e-13 * want_n2
+    # norm only (no residual vector written) and residual only (no norm)
+    n2b = torch.zeros(1, dtype=torch.float64, device=DEV)
+    ops.csr_residual_norm2(dA, dx, db, None, part, n2b)
+    assert n2b.item() == n2.item()                               # deterministic reduction
+    r2 = torch.empty_like(r)
+    ops.csr_residual_norm2(dA, dx, db, r2, None, None)
+    assert torch.equal(r, r2)
+    for omega in (1.0, 0.8):
+        out = torch.empty_like(dx)
+        ops.csr_jacobi(dA, dx, db, omega, out)
+        assert np.array_equal(out.cpu().numpy(), K.jacobi(A, x, b, omega)), (name, omega)
+
+
+@pytest.mark.parametrize("name", [c for c in SQUARE if c != "poisson2d_513"] + ["poisson2d_513"])
+def test_gauss_seidel_lexicographic_bit_exact(name):
+    A = case(name)
+    rng = np.random.default_rng(7)
+    n = A.shape[0]
+    x, b = rng.standard_normal(n), rng.standard_normal(n)
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    sched = ops.build_gs_schedule(A, "lexicographic", DEV)
+    dx = dev(x.copy())
+    ops.csr_gs_schedule(dA, dx, dev(b), sched, sweeps=2)
+    want = x.copy()
+    K.gs_forward(A, want, b, 2)
+    assert np.array_equal(dx.cpu().numpy(), want), name
+    # every set is independent in A + A^T
+    S = (abs(A) + abs(A.T)).tocsr()
+    S.setdiag(0)
+    S.eliminate_zeros()
+    lab = np.empty(n, dtype=np.int64)
+    rows = sched.d_rows.cpu().numpy()
+    for s in range(sched.nsets):
+        lab[rows[sched.h_ptr[s]:sched.h_ptr[s + 1]]] = s
+    coo = S.tocoo()
+    assert np.all(lab[coo.row] != lab[coo.col])
+
+
+def test_gauss_seidel_wide_sets_use_per_set_launches():
+    # 513^2 has 1025 anti-diagonal sets of up to 513 rows -> single-workgroup path;
+    # a 2100^2 grid has sets of up to 2100 rows (> 2048) -> per-set launch path.
+    A, _ = P.poisson_2d_structured(2100 - 1)
+    A = K.as_csr(A)
+    n = A.shape[0]
+    rng = np.random.default_rng(8)
+    x, b = rng.standard_normal(n), rng.standard_normal(n)
+    sched = ops.build_gs_schedule(A, "lexicographic", DEV)
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    dx = dev(x.copy())
+    ops.csr_gs_schedule(dA, dx, dev(b), sched, sweeps=1)
+    want = x.copy()
+    K.gs_forward(A, want, b, 1)
+    assert sched.max_set > 2048
+    assert np.array_equal(dx.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("name", ["poisson2d_513", "ragged_1000", "poisson1d_1025"])
+def test_gauss_seidel_multicolor_matches_cpu_twin(name):
+    A = case(name)
+    rng = np.random.default_rng(9)
+    n = A.shape[0]
+    x, b = rng.standard_normal(n), rng.standard_normal(n)
+    sched = ops.build_gs_schedule(A, "multicolor", DEV)
+    if name == "poisson2d_513":
+        assert sched.nsets <= 4                                   # ~red-black (+ boundary colour)
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    dx = dev(x.copy())
+    ops.csr_gs_schedule(dA, dx, dev(b), sched, sweeps=2)
+    want = x.copy()
+    order = sched.d_rows.cpu().numpy()
+    for _ in range(2):
+        K.gs_rows(A, want, b, order)
+    assert np.array_equal(dx.cpu().numpy(), want)
+    # single independent set through the plain entry point
+    dx2 = dev(x.copy())
+    rows0 = sched.d_rows[: int(sched.h_ptr[1])]
+    ops.csr_gs_rows(dA, dx2, dev(b), rows0)
+    w2 = x.copy()
+    K.gs_rows(A, w2, b, order[: int(sched.h_ptr[1])])
+    assert np.array_equal(dx2.cpu().numpy(), w2)
+
+
+def test_vector_ops():
+    rng = np.random.default_rng(10)
+    for n in (1, 2, 3, 1000, 1 << 20 | 1):
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        dy = dev(y.copy())
+        ops.axpby(0.75, dev(x), -1.5, dy)
+        assert np.array_equal(dy.cpu().numpy(), 0.75 * x + -1.5 * y)
+        dy = dev(y.copy())
+        ops.axpby(2.0, dev(x), 0.0, dy)
+        assert np.array_equal(dy.cpu().numpy(), 2.0 * x)
+        part = torch.empty(ops.partials_count(n), dtype=torch.float64, device=DEV)
+        out = torch.empty(1, dtype=torch.float64, device=DEV)
+        ops.dot(dev(x), dev(y), part, out)
+        assert abs(out.item() - float(x @ y)) <= 1e-13 * float(np.abs(x) @ np.abs(y))
+        dz = torch.empty(n, dtype=torch.float64, device=DEV)
+        ops.copy(dev(x), dz)
+        assert np.array_equal(dz.cpu().numpy(), x)
+        ops.zero(dz)
+        assert not dz.any()
+    idx = rng.permutation(5000)[:1234].astype(np.int32)
+    x = rng.standard_normal(5000)
+    buf = torch.empty(1234, dtype=torch.float64, device=DEV)
+    ops.gather(dev(idx), dev(x), buf)
+    assert np.array_equal(buf.cpu().numpy(), x[idx])
+    tgt = dev(np.zeros(5000))
+    ops.scatter(dev(idx), buf, tgt)
+    w = np.zeros(5000)
+    w[idx] = x[idx]
+    assert np.array_equal(tgt.cpu().numpy(), w)
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (7, 5), (300, 300), (513, 513), (1000, 1024)])
+def test_dense_gemv(n, m):
+    rng = np.random.default_rng(11)
+    M, x = rng.standard_normal((n, m)), rng.standard_normal(m)
+    y = torch.empty(n, dtype=torch.float64, device=DEV)
+    ops.dense_gemv(dev(M), dev(x), y)
+    want = K.dense_gemv(M, x)
+    scale = np.abs(M) @ np.abs(x)
+    assert np.all(np.abs(y.cpu().numpy() - want) <= 1e-14 * scale)
+
+
+@pytest.mark.parametrize("n", [0, 1, 5, 4096, 4097, 100000, 16785409 // 4])
+def test_exclusive_scan_bit_exact(n):
+    rng = np.random.default_rng(12)
+    a = rng.integers(0, 30, size=n).astype(np.int32)
+    out = torch.empty(n + 1, dtype=torch.int32, device=DEV)
+    ops.exclusive_scan_i32(dev(a) if n else torch.empty(0, dtype=torch.int32, device=DEV), out)
+    want = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(a, out=want[1:])
+    assert np.array_equal(out.cpu().numpy().astype(np.int64), want)
+
+
+SPGEMM = ["RA_2d", "RA_P_2d", "QtA_l2like", "QtAQ_l2like", "RA_1d", "ragged_sq", "ragged_medium",
+          "empty_rows"]
+
+
+@functools.lru_cache(maxsize=None)
+def spgemm_case(name):
+    if name in ("RA_2d", "RA_P_2d", "QtA_l2like", "QtAQ_l2like"):
+        A2, _ = P.poisson_2d_structured(64)
+        if name.startswith("RA"):
+            Pm = P.tensor_interpolator_2d(65)
+        else:
+            Pm = P.learned_like(sp.kron(P.pseudo_l2_interpolator_1d(65),
+                                        P.pseudo_l2_interpolator_1d(65)).tocsr(), 43)
+        R = Pm.T.tocsr()
+        return (R, A2) if name in ("RA_2d", "QtA_l2like") else (sp.csr_matrix(R @ A2), Pm)
+    if name == "RA_1d":
+        return P.geometric_interpolator_1d(1025).T.tocsr(), P.poisson_1d_fd(1024)[0]
+    if name == "ragged_sq":                      # one row far beyond the capacity limit
+        rag = ragged_matrix(3000, 3, long_row=17)
+        return rag, rag
+    if name == "ragged_medium":                  # ~2000 products in one row: 256-thread class
+        med = ragged_matrix(3000, 4, long_row=29, long_len=300)
+        return med, med
+    if name == "empty_rows":
+        return sp.csr_matrix((5, 4)), sp.csr_matrix((4, 6))
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", SPGEMM)
+def test_spgemm_matches_scipy_bit_exact(name):
+    A, B = (K.as_csr(m) for m in spgemm_case(name))
+    dA, dB = ops.DeviceCSR.from_scipy(A, DEV), ops.DeviceCSR.from_scipy(B, DEV)
+    plan = ops.SpGEMMPlan(dA, dB)
+    if plan.max_products > 8192:
+        pytest.skip("row exceeds LMG_SPGEMM_MAX_ROW_PRODUCTS (documented limit)")
+    C = plan.numeric(dA, dB).to_scipy()
+    want = sp.csr_matrix(A @ B)
+    want.sort_indices()
+    assert C.shape == want.shape
+    Cs = C.copy()
+    Cs.sort_indices()
+    assert np.array_equal(Cs.indices, C.indices)               # rows come out sorted
+    Cs.sum_duplicates()
+    assert Cs.nnz == C.nnz                                     # ... and duplicate-free
+    # structural pattern of C contains SciPy's (SciPy drops entries that cancel to 0.0)
+    assert abs(C - want).max() == 0.0, name
+    Cz = C.copy()
+    Cz.eliminate_zeros()
+    wz = want.copy()
+    wz.eliminate_zeros()
+    assert np.array_equal(Cz.indptr, wz.indptr) and np.array_equal(Cz.indices, wz.indices)
+    assert np.array_equal(Cz.data, wz.data)
+    # numeric-only rebuild with new values of A, same pattern
+    A2 = A.copy()
+    A2.data = A2.data * 1.5 + 0.25
+    C2 = plan.numeric(ops.DeviceCSR.from_scipy(A2, DEV, canonical=False), dB).to_scipy()
+    w2 = sp.csr_matrix(A2 @ B)
+    assert abs(C2 - w2).max() == 0.0
+
+
+def test_spgemm_capacity_error_is_loud():
+    n = 200
+    A = sp.csr_matrix(np.ones((1, n)))
+    B = sp.csr_matrix(np.ones((n, 100)))
+    dA, dB = ops.DeviceCSR.from_scipy(A, DEV), ops.DeviceCSR.from_scipy(B, DEV)
+    from learnmultigrid_amd._lib import LmgError
+    with pytest.raises(LmgError):
+        ops.SpGEMMPlan(dA, dB)
+
+
+def test_graph_capture_replays_a_sweep_sequence():
+    A, b = P.poisson_2d_structured(128)
+    A = K.as_csr(A)
+    n = A.shape[0]
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    db = dev(b.ravel())
+    x0 = torch.zeros(n, dtype=torch.float64, device=DEV)
+    x1 = torch.empty_like(x0)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        g = ops.CapturedGraph()
+        with g:
+            ops.csr_jacobi(dA, x0, db, 0.8, x1)
+            ops.csr_jacobi(dA, x1, db, 0.8, x0)
+        for _ in range(3):
+            g.launch()
+    st.synchronize()
+    want = np.zeros(n)
+    for _ in range(6):
+        want = K.jacobi(A, want, b, 0.8)
+    assert np.array_equal(x0.cpu().numpy(), want)
+
+
+def test_torch_custom_ops_registered():
+    ops.register_torch_ops()
+    A, b = P.poisson_2d_structured(32)
+    A = K.as_csr(A)
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    x = dev(np.linspace(0, 1, A.shape[0]))
+    out = torch.ops.lmg.csr_jacobi(dA.rowptr, dA.colidx, dA.vals, x, dev(b.ravel()), 1.0)
+    assert np.array_equal(out.cpu().numpy(), K.jacobi(A, x.cpu().numpy(), b, 1.0))
+    r, n2 = torch.ops.lmg.csr_residual(dA.rowptr, dA.colidx, dA.vals, x, dev(b.ravel()))
+    wr, wn2 = K.residual(A, x.cpu().numpy(), b)
+    assert np.array_equal(r.cpu().numpy(), wr)
+    y = torch.ops.lmg.csr_spmv(dA.rowptr, dA.colidx, dA.vals, A.shape[1], x)
+    assert np.array_equal(y.cpu().numpy(), A @ x.cpu().numpy())

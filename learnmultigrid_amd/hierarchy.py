@@ -1,0 +1,288 @@
+"""Device-resident multigrid hierarchy and the V-cycle executor.
+
+The reference rebuilds everything inside every cycle (Multigrid.py:91-106: transfer
+operator lookup, `i.T @ A @ i`, SuperLU factorisation -- its own TODOs at :22-23).
+Here that is the SETUP phase, done once per (matrix, transfers):
+    P_l        uploaded as CSR (any scipy.sparse / ndarray input),
+    R_l = P_l^T as an explicit CSR (restriction becomes a gather SpMV: deterministic,
+               no atomics),
+    A_{l+1} = (R_l A_l) P_l   by the device SpGEMM (lmg_spgemm_*), evaluated left to
+               right like SciPy evaluates `i.T @ A @ i`,
+    coarsest   A_L^-1 formed once on the device (dense, fp64) and applied per cycle by
+               lmg_dense_gemv plus `coarse_refine` steps of iterative refinement
+               (replaces `spsolve(A_coarse, res_coarse)` of Multigrid.py:106).
+The SOLVE phase (Multigrid.py:77-124) then only launches bandwidth-bound kernels on
+vectors that never leave HBM, and can be captured into a hipGraph.
+"""
+import math
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import ops
+from .ops import DeviceCSR, F64
+
+MAX_DENSE_COARSE = 46000      # 46000^2 * 8 B = 17 GB of the 288 GB HBM
+
+
+def _to_csr_host(M):
+    """csr_matrix(...) exactly like SemiGeometricMG.__init__ (Multigrid.py:182): dense
+    inputs lose their zeros, sparse inputs keep explicit zeros."""
+    M = sp.csr_matrix(M, dtype=np.float64)
+    if not M.has_canonical_format:
+        M = M.copy()
+        M.sum_duplicates()
+    return M
+
+
+def csr_to_dense(A):
+    n, m = A.shape
+    dense = torch.zeros((n, m), dtype=F64, device=A.device)
+    rows = torch.repeat_interleave(torch.arange(n, device=A.device),
+                                   (A.rowptr[1:] - A.rowptr[:-1]).long())
+    dense.index_put_((rows, A.colidx.long()), A.vals, accumulate=True)
+    return dense
+
+
+_INV_LEAF = 512
+
+
+def _inv_schur(A):
+    """Recursive 2x2 Schur-complement inversion: only small leaf inversions and plain
+    rocBLAS GEMMs (torch.matmul).  No pivoting across blocks -- fine for the M-matrix-like
+    Galerkin operators this is used on; dense_inverse() verifies and repairs the result."""
+    n = A.shape[0]
+    if n <= _INV_LEAF:
+        return torch.linalg.inv(A)
+    k = n // 2
+    A11, A12, A21, A22 = A[:k, :k], A[:k, k:], A[k:, :k], A[k:, k:]
+    I11 = _inv_schur(A11.contiguous())
+    T = I11 @ A12
+    IS = _inv_schur((A22 - A21 @ T).contiguous())
+    W = IS @ (A21 @ I11)
+    out = torch.empty_like(A)
+    out[k:, k:] = IS
+    out[k:, :k] = -W
+    out[:k, k:] = -(T @ IS)
+    out[:k, :k] = I11 + T @ W
+    return out
+
+
+def dense_inverse(dense, polish=2, tol=1e-9):
+    """A^-1 on the device (SETUP phase of the coarsest level / DirectSolver).
+
+    rocSOLVER's getri/getrs path (torch.linalg.inv / lu_solve) is used while it works, but
+    it cannot get its trsm workspace for n ~ 16 000 on this stack (HIPBLAS_STATUS_ALLOC_FAILED),
+    so large operators are inverted by block Schur recursion on GEMMs, polished by `polish` Newton-Schulz steps
+    M <- M (2I - A M), and verified: max|I - A M| must drop below `tol`, otherwise a pure
+    Newton-Schulz iteration from A^T/(|A|_1 |A|_inf) (convergent for every nonsingular A)
+    takes over; if that fails too the operator is reported singular."""
+    n = dense.shape[0]
+    eye = torch.eye(n, dtype=F64, device=dense.device)
+
+    def defect(M):
+        return float((eye - dense @ M).abs().max())
+
+    try:                                   # pivoted LU (rocSOLVER) while it can get workspace
+        M = torch.linalg.inv(dense)
+        steps = 0
+    except RuntimeError:
+        M = _inv_schur(dense)
+        steps = polish
+    ok = bool(torch.isfinite(M).all())
+    if ok:
+        for _ in range(steps):
+            M = M @ (2.0 * eye - dense @ M)
+        ok = bool(torch.isfinite(M).all()) and defect(M) < tol
+    if not ok:
+        M = dense.t().contiguous() / (dense.abs().sum(0).max() * dense.abs().sum(1).max())
+        for _ in range(200):
+            M = M @ (2.0 * eye - dense @ M)
+            if defect(M) < 1e-12:
+                break
+        if not bool(torch.isfinite(M).all()) or defect(M) >= tol:
+            raise ValueError("coarsest operator is numerically singular (cannot be inverted)")
+    return M.contiguous()
+
+
+class Level:
+    __slots__ = ("n", "A", "P", "R", "x", "b", "r", "tmp", "plan_RA", "plan_RAP", "RA",
+                 "gs_sched", "host_pattern")
+
+    def __init__(self, A):
+        self.n = A.shape[0]
+        self.A = A
+        self.P = self.R = None
+        self.plan_RA = self.plan_RAP = self.RA = None
+        dev = A.device
+        self.x = torch.zeros(self.n, dtype=F64, device=dev)
+        self.b = torch.zeros(self.n, dtype=F64, device=dev)
+        self.r = torch.zeros(self.n, dtype=F64, device=dev)
+        self.tmp = torch.zeros(self.n, dtype=F64, device=dev)
+        self.gs_sched = {}
+        self.host_pattern = None
+
+
+class Hierarchy:
+    """levels[0] is the fine grid; transfers[l] (n_l x n_{l+1}) prolongates level l+1 -> l."""
+
+    def __init__(self, A, transfers, device, coarse_refine=1, verbose=False):
+        self.device = torch.device(device)
+        self.coarse_refine = int(coarse_refine)
+        self.verbose = verbose
+        # every launch of this hierarchy goes to one explicit HIP stream (the legacy default
+        # stream cannot be captured into a hipGraph)
+        self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        A0 = A if isinstance(A, DeviceCSR) else DeviceCSR.from_scipy(A, self.device)
+        self.levels = [Level(A0)]
+        if isinstance(A, DeviceCSR):
+            self.levels[0].host_pattern = None
+        else:
+            Ah = _to_csr_host(A)
+            self.levels[0].host_pattern = (Ah.indptr.astype(np.int32), Ah.indices.astype(np.int32))
+        for P in transfers:
+            lev = self.levels[-1]
+            Ph = _to_csr_host(P)
+            if Ph.shape[0] != lev.n:
+                raise ValueError("transfer operator of level %d has %d rows, level has %d unknowns"
+                                 % (len(self.levels) - 1, Ph.shape[0], lev.n))
+            Rh = Ph.T.tocsr()
+            Rh.sort_indices()
+            lev.P = DeviceCSR.from_scipy(Ph, self.device)
+            lev.R = DeviceCSR.from_scipy(Rh, self.device)
+            lev.plan_RA = ops.SpGEMMPlan(lev.R, lev.A)
+            lev.RA = lev.plan_RA.numeric(lev.R, lev.A)
+            lev.plan_RAP = ops.SpGEMMPlan(lev.RA, lev.P)
+            Ac = lev.plan_RAP.numeric(lev.RA, lev.P)
+            self.levels.append(Level(Ac))
+        self.partials = torch.empty(ops.partials_count(self.levels[0].n), dtype=F64, device=self.device)
+        self.outer_r = torch.zeros(self.levels[0].n, dtype=F64, device=self.device)
+        self.norm2 = torch.zeros(1, dtype=F64, device=self.device)
+        self._factor_coarsest()
+        self._graphs = {}
+
+    # ------------------------------------------------------------------ setup ----------
+    @property
+    def sizes(self):
+        return [lev.n for lev in self.levels]
+
+    def _factor_coarsest(self):
+        Ac = self.levels[-1].A
+        n = Ac.shape[0]
+        if n > MAX_DENSE_COARSE:
+            raise ValueError("coarsest level has %d unknowns (> %d): use more levels" % (n, MAX_DENSE_COARSE))
+        self.coarse_inv = dense_inverse(csr_to_dense(Ac))
+
+    def rebuild_numeric(self, new_vals):
+        """Galerkin rebuild after the VALUES of the fine matrix changed (same pattern):
+        numeric SpGEMM passes only, then the coarse factorisation (config #5)."""
+        A0 = self.levels[0].A
+        if new_vals.numel() != A0.nnz:
+            raise ValueError("rebuild_numeric needs the same sparsity pattern")
+        A0.vals.copy_(new_vals)
+        for l in range(len(self.levels) - 1):
+            lev = self.levels[l]
+            lev.plan_RA.numeric(lev.R, lev.A, out=lev.RA)
+            lev.plan_RAP.numeric(lev.RA, lev.P, out=self.levels[l + 1].A)
+        self._factor_coarsest()
+        self._graphs = {}
+
+    def gs_schedule(self, l, kind):
+        lev = self.levels[l]
+        if kind not in lev.gs_sched:
+            if lev.host_pattern is None:
+                lev.host_pattern = (lev.A.rowptr.cpu().numpy(), lev.A.colidx.cpu().numpy())
+            rp, ci = lev.host_pattern
+            pat = sp.csr_matrix((np.ones(ci.size, dtype=np.int8), ci, rp), shape=lev.A.shape)
+            lev.gs_sched[kind] = ops.build_gs_schedule(pat, kind, self.device)
+        return lev.gs_sched[kind]
+
+    # ------------------------------------------------------------------ solve ----------
+    def smooth(self, l, smoother, steps, omega, gs_mode):
+        lev = self.levels[l]
+        if steps <= 0:
+            return
+        if smoother == "GaussSeidel":
+            ops.csr_gs_schedule(lev.A, lev.x, lev.b, self.gs_schedule(l, gs_mode), steps)
+        elif smoother == "Jacobi":
+            for _ in range(steps):
+                ops.csr_jacobi(lev.A, lev.x, lev.b, omega, lev.tmp)
+                lev.x, lev.tmp = lev.tmp, lev.x
+        else:
+            raise ValueError("unknown smoother %r" % (smoother,))
+
+    def coarse_solve(self):
+        lev = self.levels[-1]
+        ops.dense_gemv(self.coarse_inv, lev.b, lev.x)
+        for _ in range(self.coarse_refine):
+            ops.csr_residual_norm2(lev.A, lev.x, lev.b, lev.r, None, None)
+            ops.dense_gemv(self.coarse_inv, lev.r, lev.tmp)
+            ops.axpby(1.0, lev.tmp, 1.0, lev.x)
+
+    def cycle(self, smoother, steps, omega=1.0, gs_mode="lexicographic", l=0, depth=None,
+              after_presmooth=None):
+        """One V(steps, steps) cycle on level l: levels[l].x is the iterate, levels[l].b the
+        right-hand side (Multigrid.py:77-124).  depth = number of grids used."""
+        last = (len(self.levels) if depth is None else depth) - 1
+        lev, nxt = self.levels[l], self.levels[l + 1]
+        self.smooth(l, smoother, steps, omega, gs_mode)                       # :88
+        if after_presmooth is not None:
+            after_presmooth(lev.x)
+        ops.csr_residual_norm2(lev.A, lev.x, lev.b, lev.r, None, None)        # :90
+        ops.csr_spmv(lev.R, lev.r, nxt.b, 1.0, 0.0)                           # :93
+        if l + 1 == last:
+            self.coarse_solve()                                               # :106
+        else:
+            ops.zero(nxt.x)                                                   # :103
+            self.cycle(smoother, steps, omega, gs_mode, l + 1, depth)
+        ops.csr_spmv(lev.P, nxt.x, lev.x, 1.0, 1.0)                           # :115
+        self.smooth(l, smoother, steps, omega, gs_mode)                       # :121
+
+    def residual_norm(self, want_vector=True):
+        """||b - A x||_2 on the fine level (Multigrid.py:62-63); one 8-byte D2H copy."""
+        lev = self.levels[0]
+        ops.csr_residual_norm2(lev.A, lev.x, lev.b, self.outer_r if want_vector else None,
+                               self.partials, self.norm2)
+        return math.sqrt(self.norm2.item())
+
+    def captured_cycle(self, smoother, steps, omega, gs_mode):
+        """The same launch sequence as cycle(), captured once into a hipGraph and replayed."""
+        key = (smoother, steps, omega, gs_mode)
+        g = self._graphs.get(key)
+        if g is None:
+            if smoother == "GaussSeidel":
+                for l in range(len(self.levels) - 1):
+                    self.gs_schedule(l, gs_mode)            # host work must not happen in capture
+            before = [(lev.x, lev.tmp) for lev in self.levels]
+            g = ops.CapturedGraph()
+            with g:
+                self.cycle(smoother, steps, omega, gs_mode)
+            after = [(lev.x, lev.tmp) for lev in self.levels]
+            if any(a[0] is not b[0] for a, b in zip(before, after)):
+                raise RuntimeError("ping-pong buffers did not return to their slots")
+            self._graphs[key] = g
+        return g
+
+    def memory_bytes(self):
+        tot = 0
+        for lev in self.levels:
+            tot += lev.A.bytes() + 4 * 8 * lev.n
+            for M in (lev.P, lev.R, lev.RA):
+                if M is not None:
+                    tot += M.bytes()
+        return tot + self.coarse_inv.numel() * 8
+
+    def cycle_bytes(self, steps):
+        """Algorithmic HBM bytes of one V(steps,steps) cycle: per level
+        (2*steps+1) sweeps + restriction + prolongation; coarsest dense apply separately."""
+        tot = 0
+        for lev in self.levels[:-1]:
+            n, nnz = lev.n, lev.A.nnz
+            nc = lev.P.shape[1]
+            tot += (2 * steps + 1) * (12 * nnz + 4 * (n + 1) + 24 * n)
+            tot += 12 * lev.R.nnz + 4 * (nc + 1) + 8 * n + 8 * nc
+            tot += 12 * lev.P.nnz + 4 * (n + 1) + 8 * nc + 16 * n
+        nL = self.levels[-1].n
+        coarse = (1 + self.coarse_refine) * 8 * nL * nL
+        return tot, coarse

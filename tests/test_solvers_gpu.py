@@ -1,0 +1,261 @@
+"""The drop-in solver classes on an MI355X against (a) golden vectors captured from the
+reference and (b) the CPU oracle on seeded inputs (-m gpu).
+
+Bar (BASELINE.json north_star): level indexing bit-exact; per-iteration residual norms
+within 1e-10 relative.  Entries that sit at the rounding floor of a run (<= 1e-14 of the
+largest entry) cannot be reproduced to any relative accuracy by anybody, including the
+reference run twice with a different BLAS, hence the absolute floor.
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden, coo_from                      # noqa: E402
+from learnmultigrid_amd import problems as P                     # noqa: E402
+from learnmultigrid_amd.solvers import (DirectSolver, Jacobi, GaussSeidel, GeometricMG,  # noqa: E402
+                                        SemiGeometricMG, HierarchyMG, Multigrid)
+from oracle import vcycle_ref as V                               # noqa: E402  (checker only)
+
+RTOL = 1e-10
+
+
+def assert_track(got, want, rtol=RTOL, floor=1e-14):
+    assert got.shape == want.shape, (got.shape, want.shape)
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=floor * float(np.max(want)))
+
+
+def test_g1_small_solvers_match_reference():
+    g = load_golden("g1_small_solvers")
+    A, rhs = g["A"], g["rhs"]
+    d = DirectSolver(A, rhs)
+    d.solve()
+    np.testing.assert_allclose(d.get_solution(), g["direct_solution"], rtol=1e-13)
+    assert d.get_residual() <= 1e-14
+    j = Jacobi(A, rhs)
+    j.solve()
+    assert j.get_iterations() == int(g["jacobi_iterations"])
+    assert_track(j.get_track_res(), g["jacobi_track"])
+    np.testing.assert_allclose(j.get_solution(), g["jacobi_solution"], rtol=1e-12)
+    s = GaussSeidel(A, rhs)
+    s.solve()
+    assert s.get_iterations() == int(g["gs_iterations"])
+    assert_track(s.get_track_res(), g["gs_track"], 1e-9)
+    np.testing.assert_allclose(s.get_solution(), g["gs_solution"], rtol=1e-12)
+    assert s.get_track_res().shape[1] == 1 and s.get_dimension() == 3
+
+
+@pytest.mark.parametrize("ne", [16, 64, 1024])
+def test_g2_residual_histories_match_reference(ne):
+    g = load_golden("g2_poisson1d_ne%d" % ne)
+    A, rhs = coo_from(g, "A"), g["rhs"]
+    for kind in ("pseudo", "quasi"):
+        Q = coo_from(g, "Q_" + kind)
+        for levels, steps in ((2, 1), (2, 3), (3, 1)):
+            key = "semi_%s_L%d_s%d" % (kind, levels, steps)
+            m = SemiGeometricMG(A, rhs, Q)
+            m.solve(smoother="GaussSeidel", smooth_steps=steps, levels=levels,
+                    max_iterations=100, error=1e-11)
+            assert m.get_iterations() == int(g[key + "_iterations"]), key
+            assert_track(m.get_track_res(), g[key + "_track"])
+            np.testing.assert_allclose(m.get_solution(), g[key + "_solution"], rtol=1e-9, atol=1e-13)
+            assert m.level_dims[0] == ne + 1 and m.level_dims[1] == Q.shape[1]
+    for levels, steps in ((2, 1), (3, 3), (4, 2)):
+        key = "geo_L%d_s%d" % (levels, steps)
+        m = GeometricMG(A, rhs)
+        m.solve(smoother="GaussSeidel", smooth_steps=steps, levels=levels,
+                max_iterations=100, error=1e-11)
+        assert m.get_iterations() == int(g[key + "_iterations"]), key
+        assert_track(m.get_track_res(), g[key + "_track"])
+        assert m.level_dims == V.level_sizes(ne + 1, levels)            # bit-exact level indexing
+    m = GeometricMG(A, rhs)
+    m.solve()                                     # defaults: name "Jacobi" ignored as shipped
+    assert m.get_iterations() == int(g["geo_default_iterations"])
+    assert_track(m.get_track_res(), g["geo_default_track"])
+    assert m.get_track_res()[0, 0] == np.sqrt(ne + 1)                   # iteration-1 quirk
+
+
+@pytest.mark.parametrize("ne", [16, 64])
+def test_g2_initial_guess_and_vcycle_signature(ne):
+    g = load_golden("g2_poisson1d_ne%d" % ne)
+    A, rhs = coo_from(g, "A"), g["rhs"]
+    x0 = g["x0"].copy()
+    m = GeometricMG(A, rhs)
+    m.solve(levels=2, smooth_steps=2, max_iterations=3, error=1e-30, initial_guess=x0)
+    assert_track(m.get_track_res(), g["geo_x0_track"])
+    np.testing.assert_allclose(m.get_solution(), g["geo_x0_solution"], rtol=1e-10, atol=1e-14)
+    assert np.array_equal(x0, g["x0"])                                   # not mutated by default
+    m = GeometricMG(A, rhs)
+    m.solve(levels=2, smooth_steps=2, max_iterations=3, error=1e-30, initial_guess=x0,
+            mutate_initial_guess=True)
+    np.testing.assert_allclose(x0, g["geo_x0_mutated_guess"], rtol=1e-11, atol=1e-15)
+    m = GeometricMG(A, rhs)
+    u0 = np.zeros((ne + 1, 1))
+    u = m.v_cycle(m.get_matrix(), u0, rhs, "GaussSeidel", 2, 1e-8, 2)
+    np.testing.assert_allclose(u, g["vcycle_u"], rtol=1e-11, atol=1e-15)
+    np.testing.assert_allclose(u0, g["vcycle_u0_after"], rtol=1e-11, atol=1e-15)
+
+
+@pytest.mark.parametrize("ne", [16, 64, 1024])
+def test_g2_standalone_smoothers(ne):
+    g = load_golden("g2_poisson1d_ne%d" % ne)
+    A, rhs = coo_from(g, "A"), g["rhs"]
+    j = Jacobi(A, rhs)
+    j.solve(max_iterations=25)
+    assert_track(j.get_track_res(), g["jacobi25_track"])
+    np.testing.assert_allclose(j.get_solution(), g["jacobi25_solution"], rtol=1e-12, atol=1e-18)
+    if ne <= 64:
+        s = GaussSeidel(A, rhs)
+        s.solve(max_iterations=25)
+        assert_track(s.get_track_res(), g["gs25_track"])
+        np.testing.assert_allclose(s.get_solution(), g["gs25_solution"], rtol=1e-11, atol=1e-18)
+
+
+@pytest.mark.parametrize("ne", [32, 256])
+def test_g3_learned_like_q_matches_reference(ne):
+    g = load_golden("g3_fem1d_ne%d" % ne)
+    A, rhs = coo_from(g, "A"), g["rhs"]
+    for name in ("learned", "quasi"):
+        Q = coo_from(g, "Q_" + name)
+        m = SemiGeometricMG(A, rhs, Q)
+        m.solve(levels=2, smoother="GaussSeidel", smooth_steps=3, error=1e-10, max_iterations=15)
+        assert m.get_iterations() == int(g[name + "_iterations"])
+        assert_track(m.get_track_res(), g[name + "_track"])
+    # dense Q input (the reference scripts pass ndarrays) gives the same run
+    m2 = SemiGeometricMG(A.toarray(), rhs, coo_from(g, "Q_learned").toarray())
+    m2.solve(levels=2, smoother="GaussSeidel", smooth_steps=3, error=1e-10, max_iterations=15)
+    assert_track(m2.get_track_res(), g["learned_track"])
+
+
+def oracle_run(A, rhs, hier, **kw):
+    ref = V.RefMultigrid(A, rhs.copy(), hierarchy=hier)
+    ref.solve(**kw)
+    return ref
+
+
+@pytest.mark.parametrize("m,levels", [(64, 3), (128, 4)])
+@pytest.mark.parametrize("mode", ["as_shipped", "jacobi", "gs_named"])
+def test_2d_structured_hierarchy_matches_oracle(m, levels, mode):
+    A, rhs = P.poisson_2d_structured(m)
+    hier = P.geometric_hierarchy_2d(m + 1, levels)
+    kw = dict(levels=levels, smooth_steps=3, max_iterations=12, error=1e-9)
+    if mode == "as_shipped":
+        okw = dict(smoother="Jacobi", semantics="as_shipped")
+        gkw = dict(smoother="Jacobi")
+    elif mode == "jacobi":
+        okw = dict(smoother="Jacobi", semantics="as_named", omega=0.8)
+        gkw = dict(smoother="Jacobi", smoother_semantics="as_named", omega=0.8)
+    else:
+        okw = dict(smoother="GaussSeidel", semantics="as_named")
+        gkw = dict(smoother="GaussSeidel", smoother_semantics="as_named")
+    ref = oracle_run(A, rhs, hier, **kw, **okw)
+    mg = HierarchyMG(A, rhs.copy(), hier)
+    mg.solve(**kw, **gkw)
+    assert mg.get_iterations() == ref.iterations
+    assert_track(mg.get_track_res(), ref.track_res)
+    assert mg.level_dims == ref.level_dims == [s * s for s in P.level_sizes(m + 1, levels)]
+    np.testing.assert_allclose(mg.get_solution(), ref.solution, rtol=1e-9, atol=1e-13)
+    assert mg.get_track_res()[-1, 0] < 1e-4 * mg.get_track_res()[1, 0]   # it actually converges
+
+
+def test_cfg2_513_three_levels_jacobi_and_graph_replay():
+    """BASELINE config #2: 2-D structured P1 Poisson 512x512, 3-level V-cycle, geometric transfer."""
+    m, levels = 512, 3
+    A, rhs = P.poisson_2d_structured(m)
+    hier = P.geometric_hierarchy_2d(m + 1, levels)
+    kw = dict(levels=levels, smoother="Jacobi", smooth_steps=3, max_iterations=8, error=1e-9)
+    ref = oracle_run(A, rhs, hier, semantics="as_named", omega=0.8, **kw)
+    mg = HierarchyMG(A, rhs.copy(), hier)
+    mg.solve(smoother_semantics="as_named", omega=0.8, **kw)
+    assert_track(mg.get_track_res(), ref.track_res)
+    assert mg.level_dims == [513 * 513, 257 * 257, 129 * 129]
+    mg2 = HierarchyMG(A, rhs.copy(), hier)
+    mg2.solve(smoother_semantics="as_named", omega=0.8, use_graph=True, **kw)
+    assert np.array_equal(mg2.get_track_res(), mg.get_track_res())       # hipGraph replay == eager
+    assert np.array_equal(mg2.get_solution(), mg.get_solution())
+
+
+def test_learned_like_hierarchy_2d_matches_oracle():
+    m, levels = 96, 4                                                    # 97 -> 49 -> 25 -> 13
+    A, rhs = P.jittered_poisson_2d(m, seed=42)
+    sizes = P.level_sizes(m + 1, levels)
+    hier = []
+    for l, s in enumerate(sizes[:-1]):
+        base = sp.kron(P.pseudo_l2_interpolator_1d(s), P.pseudo_l2_interpolator_1d(s)).tocsr()
+        hier.append(P.learned_like(base, 43 + l))
+    kw = dict(levels=levels, smoother="GaussSeidel", smooth_steps=3, max_iterations=10, error=1e-9)
+    ref = oracle_run(A, rhs, hier, semantics="as_shipped", **kw)
+    mg = HierarchyMG(A, rhs.copy(), hier)
+    mg.solve(**kw)
+    assert mg.get_iterations() == ref.iterations
+    assert_track(mg.get_track_res(), ref.track_res)
+
+
+def test_multicolor_gs_converges_and_is_deterministic():
+    A, rhs = P.poisson_2d_structured(128)
+    hier = P.geometric_hierarchy_2d(129, 4)
+    runs = []
+    for _ in range(2):
+        mg = HierarchyMG(A, rhs.copy(), hier)
+        mg.solve(levels=4, smoother="GaussSeidel", smooth_steps=2, max_iterations=12, error=1e-9,
+                 smoother_semantics="as_named", gs_mode="multicolor")
+        runs.append(mg.get_track_res())
+    assert np.array_equal(runs[0], runs[1])
+    assert runs[0][-1, 0] <= 1e-9 or runs[0][-1, 0] < 1e-7 * runs[0][1, 0]
+
+
+def test_error_conventions():
+    A, rhs = P.poisson_1d_fd(16)
+    mg = GeometricMG(A, rhs)
+    with pytest.raises(ValueError):
+        mg.solve(levels=1)
+    with pytest.raises(ValueError):
+        mg.solve(cycle="W")
+    with pytest.raises(ValueError):
+        mg.solve(smoother="SOR")
+    with pytest.raises(ValueError):
+        mg.solve(smoother="CG", smoother_semantics="as_named")
+    with pytest.raises(ValueError):
+        SemiGeometricMG(A, rhs, np.ones((5, 3))).solve()
+    assert isinstance(mg, Multigrid) and mg.label == "GeometricMG"
+
+
+def test_galerkin_rebuild_numeric_only():
+    """Config #5's "RAP rebuild": new coefficients, same pattern -> numeric SpGEMM only."""
+    from learnmultigrid_amd.hierarchy import Hierarchy
+    from learnmultigrid_amd.ops import DeviceCSR
+    m, levels = 64, 3
+    A1, _ = P.jittered_poisson_2d(m, seed=42, coeff_sigma=0.5, coeff_seed=44)
+    A2, _ = P.jittered_poisson_2d(m, seed=42, coeff_sigma=0.5, coeff_seed=45)
+    assert np.array_equal(A1.indices, A2.indices)
+    hier = P.geometric_hierarchy_2d(m + 1, levels)
+    H = Hierarchy(A1, hier, "cuda:0")
+    H.rebuild_numeric(torch.from_numpy(A2.data.copy()).to("cuda:0"))
+    want = A2
+    for Pm in hier:
+        want = sp.csr_matrix(Pm.T @ want @ Pm)
+    got = H.levels[-1].A.to_scipy()
+    assert abs(got - want).max() <= 1e-13 * abs(want).max()
+
+
+def test_full_size_properties_4097():
+    """cfg#4 size (4097^2, 6 levels), size-independent properties instead of an oracle run:
+    monotone residual history with a multigrid-like factor, linearity in the rhs, and
+    agreement of the fused norm with a norm computed from the downloaded residual."""
+    m, levels = 4096, 6
+    A, rhs = P.poisson_2d_structured(m)
+    hier = P.geometric_hierarchy_2d(m + 1, levels)
+    mg = HierarchyMG(A, rhs.copy(), hier)
+    mg.solve(levels=levels, smoother="Jacobi", smooth_steps=3, max_iterations=8, error=1e-30,
+             smoother_semantics="as_named", omega=0.8, use_graph=True)
+    t = mg.get_track_res().ravel()
+    assert mg.level_dims == [s * s for s in (4097, 2049, 1025, 513, 257, 129)]
+    assert np.all(t[2:] < 0.25 * t[1:-1])                               # V(3,3) contraction
+    r = mg.get_residual_vector()
+    assert abs(np.linalg.norm(r) - t[-1]) <= 1e-12 * t[-1]
+    mg2 = HierarchyMG(A, 2.0 * rhs, hier)
+    mg2.solve(levels=levels, smoother="Jacobi", smooth_steps=3, max_iterations=8, error=1e-30,
+              smoother_semantics="as_named", omega=0.8, use_graph=True)
+    assert np.array_equal(mg2.get_solution(), 2.0 * mg.get_solution())   # exact: scaling by 2

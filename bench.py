@@ -1,15 +1,24 @@
 #!/usr/bin/env python3
-"""Headline benchmark: fine-level DoF.sweeps/s of the 2-D Poisson V-cycle path on MI355X.
+"""Headline benchmark: fine-level DoF.sweeps/s of the 2-D Poisson V-cycle on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--size 4096] [--mode sweep|vcycle]
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over the synthetic fine grid:
-  mode sweep  : one weighted-Jacobi sweep + one residual SpMV (with fused ||r||^2) on the
-                fine level of cfg#4 (4097^2 DoF 5-point P1 Poisson, CSR fp64/int32);
-  mode vcycle : one full V(nu,nu) cycle over all levels (added once the hierarchy is built).
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel:
-the fine-level Jacobi sweep, timed with HIP events on the launch stream) and
-`cpu_baseline` (the CPU oracle on the same matrix, bounded sample, 1 core).
+Workload (BASELINE.json cfg#4, the size the north-star target is quoted on; it fits one
+GPU): 2-D structured P1 Poisson, 4096x4096 elements = 4097^2 DoF, CSR fp64/int32, 6-level
+V-cycle with the tensor-product geometric transfer and Galerkin coarse operators built by
+the device SpGEMM at setup.  A "step" is ONE full V(3,3) cycle (weighted Jacobi, omega =
+0.8, "as_named" semantics) over all levels, replayed from a hipGraph: 6 Jacobi sweeps +
+1 residual SpMV on the fine level, the same on every coarser level, restrictions,
+prolongations and the dense coarsest solve.  value = fine-level DoF x fine-level sweeps
+per cycle (2*nu + 1) / time: the fine-level sweep rate the whole cycle sustains.
+
+For N > 1 the fine grid is row-block partitioned over the ranks (strong scaling: the
+problem size is fixed), halos travel over RCCL, see learnmultigrid_amd/dist.py.
+
+Extra objects on the JSON line: `roofline` (dominant kernel = fine-level Jacobi sweep,
+average launch duration measured with HIP events on the launch stream) and
+`cpu_baseline` (the CPU oracle running the same cycle on the same hierarchy, 1 core).
 """
 import argparse
 import json
@@ -22,11 +31,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s copy-achievable
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s copy-achievable
 
 
 def sweep_bytes(n, nnz):
-    """Algorithmic HBM bytes of one fine-level sweep (Jacobi or residual), SURVEY.md 8(d):
+    """Algorithmic HBM bytes of one sweep (Jacobi or residual) -- SURVEY.md 8(d):
     CSR matrix (12 B/nnz + 4 B/row) + x once + b + output."""
     return 12 * nnz + 4 * (n + 1) + 24 * n
 
@@ -34,40 +43,52 @@ def sweep_bytes(n, nnz):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=4096, help="elements per side (nodes = size+1)")
-    ap.add_argument("--mode", default="sweep", choices=["sweep"])
+    ap.add_argument("--levels", type=int, default=6)
+    ap.add_argument("--nu", type=int, default=3, help="pre/post smoothing steps")
     ap.add_argument("--omega", type=float, default=0.8)
+    ap.add_argument("--mode", default="vcycle", choices=["vcycle", "sweep"])
+    ap.add_argument("--no-graph", action="store_true", help="launch kernels from Python instead of replaying a hipGraph")
     ap.add_argument("--rpt", type=int, default=0, help="sweep kernel rows/thread (0 = library default)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--cpu-cycles", type=int, default=2, help="V-cycles timed by the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(A, rhs, omega, budget_s):
-    """The CPU oracle (oracle/lmg_oracle.c = port of the SciPy/pyamg loops the reference
-    calls) on the SAME matrix: alternating Jacobi sweep and residual, single thread."""
-    from oracle import kernels as K
-    A = K.as_csr(A)
+def cpu_baseline(A, hier, rhs, args):
+    """CPU oracle (port of the SciPy/pyamg loops the reference calls, setup hoisted like
+    on the GPU) on the SAME matrix and hierarchy, single thread."""
+    from oracle import vcycle_ref as V
     n = A.shape[0]
+    t0 = time.perf_counter()
+    H = V.HoistedVCycle(A, hier)
+    t_setup = time.perf_counter() - t0
     x = np.zeros(n)
     b = rhs.ravel()
-    K.jacobi(A, x, b, omega)                       # warm the caches / page in
-    t0 = time.perf_counter()
-    sweeps = 0
-    while True:
-        x = K.jacobi(A, x, b, omega)
-        K.residual(A, x, b)
-        sweeps += 2
+    if args.mode == "sweep":
+        from oracle import kernels as K
+        t0 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t0 < 8.0:
+            x = K.jacobi(H.A[0], x, b, args.omega)
+            K.residual(H.A[0], x, b)
+            reps += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or sweeps >= 200:
-            break
+        sweeps = 2 * reps
+        what = "%d x (Jacobi sweep + residual) on the fine level" % reps
+    else:
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_cycles):
+            x = H.cycle(x, b, "Jacobi", args.nu, args.omega)
+        dt = time.perf_counter() - t0
+        sweeps = (2 * args.nu + 1) * args.cpu_cycles
+        what = "%d full V(%d,%d) cycles, %d levels" % (args.cpu_cycles, args.nu, args.nu, len(hier) + 1)
     return {"value": n * sweeps / dt, "unit": "DoF*sweeps/s", "cores": 1, "kind": "port",
-            "sample": "%d sweeps (Jacobi+residual alternating) of the same %d-DoF matrix, %.1f s, "
-                      "oracle/lmg_oracle.c single thread; host has %d logical CPUs"
-                      % (sweeps, n, dt, os.cpu_count() or 0),
-            "GBps": sweep_bytes(n, A.nnz) * sweeps / dt / 1e9}
+            "sample": "%s of the same %d-DoF problem in %.1f s (setup %.1f s not counted), "
+                      "oracle/ single thread; host has %d logical CPUs"
+                      % (what, n, dt, t_setup, os.cpu_count() or 0)}
 
 
 def main():
@@ -75,33 +96,25 @@ def main():
     import torch
     import torch.distributed as dist
     from learnmultigrid_amd import ops, problems as P
+    from learnmultigrid_amd.hierarchy import Hierarchy
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        dist.init_process_group("nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    force_dist = os.environ.get("LMG_FORCE_DIST") == "1"     # drive the partitioned path on 1 GPU
+    if world > 1 or force_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.rpt:
         ops.tune_set("sweep_rpt", args.rpt)
 
-    m = args.size
+    m, levels, nu = args.size, args.levels, args.nu
     A, rhs = P.poisson_2d_structured(m)
+    hier = P.geometric_hierarchy_2d(m + 1, levels)
     n, nnz = A.shape[0], A.nnz
-    dA = ops.DeviceCSR.from_scipy(A, dev, canonical=False)
-    b = torch.from_numpy(rhs.ravel().copy()).to(dev)
-    x = torch.zeros(n, dtype=torch.float64, device=dev)
-    y = torch.empty_like(x)
-    r = torch.empty_like(x)
-    part = torch.empty(ops.partials_count(n), dtype=torch.float64, device=dev)
-    n2 = torch.empty(1, dtype=torch.float64, device=dev)
-
-    def step():
-        nonlocal x, y
-        ops.csr_jacobi(dA, x, b, args.omega, y)
-        x, y = y, x
-        ops.csr_residual_norm2(dA, x, b, r, part, n2)
 
     def barrier():
         torch.cuda.synchronize()
@@ -109,62 +122,114 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    sweeps_per_step = 2
-    value = world * n * sweeps_per_step * args.steps / dt
+    if world > 1 or force_dist:
+        from learnmultigrid_amd.dist import DistributedVCycle
+        t0 = time.perf_counter()
+        D = DistributedVCycle.from_problem(A, hier, dev, grid_side=m + 1)
+        setup_s = time.perf_counter() - t0
+        D.set_rhs(rhs)
+        stream = D.stream
+        with torch.cuda.stream(stream):
+            step = D.make_step("Jacobi", nu, args.omega, graph=not args.no_graph)
+        H = D.local_hierarchy
+        fine_A = D.fine_local_matrix
+        n_loc_fine = D.fine_local_rows
+    else:
+        t0 = time.perf_counter()
+        H = Hierarchy(A, hier, dev)
+        torch.cuda.synchronize()
+        setup_s = time.perf_counter() - t0
+        fine = H.levels[0]
+        fine.b.copy_(torch.from_numpy(rhs.ravel().copy()).to(dev))
+        stream = H.stream
+        stream.wait_stream(torch.cuda.current_stream())
+        fine_A = fine.A
+        n_loc_fine = n
+        with torch.cuda.stream(stream):
+            if args.mode == "sweep":
+                r = torch.empty_like(fine.x)
 
-    # ---- roofline of the dominant kernel: fine-level Jacobi sweep, HIP events on the launch stream
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = max(20, args.steps)
-    torch.cuda.synchronize()
-    ev0.record()
-    for _ in range(reps):
-        ops.csr_jacobi(dA, x, b, args.omega, y)
-        x, y = y, x
-    ev1.record()
-    torch.cuda.synchronize()
-    t_jac = ev0.elapsed_time(ev1) * 1e-3 / reps
-    ev0.record()
-    for _ in range(reps):
-        ops.csr_residual_norm2(dA, x, b, r, part, n2)
-    ev1.record()
-    torch.cuda.synchronize()
-    t_res = ev0.elapsed_time(ev1) * 1e-3 / reps
-    B = sweep_bytes(n, nnz)
+                def step():
+                    ops.csr_jacobi(fine.A, fine.x, fine.b, args.omega, fine.tmp)
+                    fine.x, fine.tmp = fine.tmp, fine.x
+                    ops.csr_residual_norm2(fine.A, fine.x, fine.b, r, H.partials, H.norm2)
+            elif args.no_graph:
+                def step():
+                    H.cycle("Jacobi", nu, args.omega)
+            else:
+                g = H.captured_cycle("Jacobi", nu, args.omega, "lexicographic")
+                step = g.launch
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        sweeps_per_step = 2 if args.mode == "sweep" else 2 * nu + 1
+        value = n * sweeps_per_step * args.steps / dt
+
+        # ---- roofline of the dominant kernel (fine-level Jacobi sweep), HIP events on this stream
+        xa = torch.zeros(fine_A.shape[1], dtype=torch.float64, device=dev)
+        ya = torch.zeros(fine_A.shape[0], dtype=torch.float64, device=dev)
+        ba = torch.ones(fine_A.shape[0], dtype=torch.float64, device=dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 40
+        for _ in range(3):
+            ops.csr_jacobi(fine_A, xa, ba, args.omega, ya)
+        torch.cuda.synchronize()
+        ev0.record(stream)
+        for _ in range(reps):
+            ops.csr_jacobi(fine_A, xa, ba, args.omega, ya)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        t_jac = ev0.elapsed_time(ev1) * 1e-3 / reps
+    B = sweep_bytes(fine_A.shape[0], fine_A.nnz)
     achieved = B / t_jac / 1e9
-    roofline = {"bound": "hbm", "kernel": "csr_sweep_kernel<JACOBI>", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None, "algorithmic_bytes_per_launch": B,
-                "avg_launch_ms": t_jac * 1e3,
-                "residual_kernel_GBps": B / t_res / 1e9, "residual_avg_launch_ms": t_res * 1e3}
+    roofline = {"bound": "hbm", "kernel": "csr_sweep_kernel<MODE_JACOBI> on the fine level",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": B, "avg_launch_ms": t_jac * 1e3,
+                "rows_per_launch": int(fine_A.shape[0])}
+    cyc_bytes, coarse_bytes = H.cycle_bytes(nu) if args.mode == "vcycle" and world == 1 else (None, None)
+    if world > 1 or force_dist:
+        out_extra = {"distributed_levels": D.n_dist, "rows_per_rank_fine": n_loc_fine,
+                     "halo_values_fine": int(D.dl[0].ghost.numel())}
+    else:
+        out_extra = {}
 
-    out = {"metric": "fine-level DoF*sweeps/s (2-D Poisson V-cycle path)", "value": value,
+    out = {"metric": "fine-level DoF*sweeps/s, 2-D Poisson V-cycle", "value": value,
            "unit": "DoF*sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "cfg#4 fine level: 2-D structured P1 Poisson %dx%d elements "
-                                  "(%d DoF, %d nnz CSR fp64/int32); step = 1 weighted-Jacobi sweep "
-                                  "(omega=%.2f) + 1 residual SpMV with fused norm" % (m, m, n, nnz, args.omega),
-                      "mode": args.mode, "sweeps_per_step": sweeps_per_step,
+           "config": {"workload": "cfg#4: 2-D structured P1 Poisson %dx%d elements (%d DoF, %d nnz, CSR "
+                                  "fp64/int32), %d-level V(%d,%d) cycle, weighted Jacobi omega=%.2f, "
+                                  "tensor-product geometric transfer, Galerkin RAP by device SpGEMM"
+                                  % (m, m, n, nnz, levels, nu, nu, args.omega),
+                      "mode": args.mode, "step": "one full V-cycle" if args.mode == "vcycle"
+                      else "1 Jacobi sweep + 1 residual on the fine level",
+                      "fine_sweeps_per_step": sweeps_per_step, "hipgraph": not args.no_graph,
+                      "level_sizes": [int(s) for s in P.level_sizes(m + 1, levels)],
+                      "partition": "row blocks of grid lines over %d rank(s)" % world,
                       "sweep_rpt": ops.tune_get("sweep_rpt")},
-           "achieved_GBps": B * sweeps_per_step * args.steps / dt / 1e9 * world,
-           "roofline": roofline}
+           "setup_s": setup_s, "roofline": roofline}
+    out["config"].update(out_extra)
+    if cyc_bytes is not None:
+        out["cycle_algorithmic_GBps"] = cyc_bytes / (dt / args.steps) / 1e9
+        out["cycle_algorithmic_bytes"] = cyc_bytes
+        out["coarse_dense_bytes"] = coarse_bytes
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(A, rhs, args.omega, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(A, hier, rhs, args)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

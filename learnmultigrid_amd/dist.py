@@ -1,0 +1,306 @@
+"""Multi-GPU V-cycle: contiguous row-block partition of every level, halo exchange over
+RCCL (torch.distributed backend "nccl" IS RCCL on ROCm), residual-norm all-reduce.
+
+The reference is single-process (no MPI / NCCL anywhere); this layer is new work defined
+by BASELINE.json's north star, designed for one node of 8 x MI355X (288 GB each,
+point-to-point xGMI links):
+
+  * SETUP IS REPLICATED.  Every rank builds the whole hierarchy on its own GPU (the
+    4097^2 hierarchy is ~3 GB, the 8193^2 one ~12 GB, of 288 GB) and slices its row
+    blocks out of it: no distributed SpGEMM, no setup-time collectives except one
+    all_gather_object of the ghost index lists.
+  * Level l is owned in contiguous row blocks; with `grid_side` the cuts fall on grid
+    lines and coarse line j lives with fine line 2j, so A, R = P^T and P all need ghosts
+    from the two neighbouring ranks only.  Each level has ONE ghost set (union of what
+    A_l, R_l and P_{l-1} reference), so every level-l vector has the layout
+    [owned rows | ghosts sorted by global index] and one exchange plan.
+  * One halo exchange = a pack kernel (lmg_gather) + one grouped batch of
+    isend / irecv (<= 2 neighbours, 32.8 KB per neighbour on the fine level of cfg#4).
+    Messages are latency-bound, not xGMI-bandwidth-bound.
+  * Levels with fewer than `replicate_below` rows (default 2 M: below that a halo
+    exchange costs more than computing the whole level redundantly) are NOT distributed: the restricted
+    residual is all-gathered once per cycle and every rank runs the rest of the cycle
+    redundantly on its replicated hierarchy, then prolongates from the full coarse
+    vector without further communication.
+  * Weighted Jacobi only: row sums are accumulated in the same storage order as on one
+    GPU, so the distributed iterate is bit-identical to the single-GPU one; only the
+    all-reduced norm differs in summation order.  Lexicographic Gauss-Seidel is
+    sequential across the partition and is refused here.
+
+The class is written against an `ops` object (default: the HIP kernels) so that the
+partition / halo / collective logic is exercised by world_size-2 gloo tests on CPU
+tensors with a test-only ops shim; the product never falls back to it.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .ops import DeviceCSR, F64, I32
+
+
+def block_bounds(n_units, world):
+    """Contiguous split of n_units into `world` blocks, sizes differing by at most 1."""
+    base, rem = divmod(n_units, world)
+    b = [0]
+    for p in range(world):
+        b.append(b[-1] + base + (1 if p < rem else 0))
+    return b
+
+
+def _rows(M, lo, hi):
+    """Rows [lo, hi) of a CSR held in tensors: (rowptr_local, colidx_global, vals)."""
+    rp = M.rowptr[lo:hi + 1].long()
+    s, e = int(rp[0]), int(rp[-1])
+    return (rp - s).to(I32), M.colidx[s:e], M.vals[s:e]
+
+
+class _DLevel:
+    pass
+
+
+class DistributedVCycle:
+    def __init__(self, full, device, ops_mod=None, grid_side=None, replicate_below=2_000_000,
+                 group=None):
+        """full: a replicated hierarchy (learnmultigrid_amd.hierarchy.Hierarchy or anything
+        with the same .levels[l].A/.P/.R, .coarse_solve(), .cycle())."""
+        if ops_mod is None:
+            from . import ops as ops_mod
+        self.ops = ops_mod
+        self.full = full
+        self.device = torch.device(device)
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.stream = getattr(full, "stream", None)
+        nlev = len(full.levels)
+        sizes = [lev.n for lev in full.levels]
+        # ---- which levels are distributed -------------------------------------------------
+        self.n_dist = 0
+        for l in range(nlev - 1):                   # the coarsest level is always replicated
+            if sizes[l] >= replicate_below and sizes[l] >= 4 * self.world:
+                self.n_dist = l + 1
+            else:
+                break
+        if self.n_dist == 0:
+            raise ValueError("problem too small to distribute (fine level has %d rows)" % sizes[0])
+        # ---- row ranges per level ------------------------------------------------------------
+        self.bounds = []
+        side = grid_side
+        for l in range(self.n_dist + 1):
+            n = sizes[l]
+            if l == 0:
+                if side is not None and side * side == n:
+                    cuts = [c * side for c in block_bounds(side, self.world)]
+                else:
+                    side = None
+                    cuts = block_bounds(n, self.world)
+            else:
+                # coarse row c lives with the rank that owns its anchor fine row (the row of
+                # the largest entry of column c of P): coarse line j stays with fine line 2j
+                R = full.levels[l - 1].R
+                anchor = self._anchors(R)
+                prev = torch.tensor(self.bounds[l - 1], device=anchor.device, dtype=anchor.dtype)
+                cm = torch.cummax(anchor, 0).values
+                cuts = torch.searchsorted(cm, prev[:-1].contiguous()).tolist() + [n]
+                cuts[0] = 0
+            self.bounds.append([int(c) for c in cuts])
+        # ---- local slices + ghost sets ---------------------------------------------------------
+        self.dl = []
+        raw = []
+        for l in range(self.n_dist):
+            lo, hi = self.bounds[l][self.rank], self.bounds[l][self.rank + 1]
+            clo, chi = self.bounds[l + 1][self.rank], self.bounds[l + 1][self.rank + 1]
+            lev = full.levels[l]
+            raw.append({"A": _rows(lev.A, lo, hi), "P": _rows(lev.P, lo, hi), "R": _rows(lev.R, clo, chi)})
+        ghosts = []
+        for l in range(self.n_dist):
+            lo, hi = self.bounds[l][self.rank], self.bounds[l][self.rank + 1]
+            cols = [raw[l]["A"][1], raw[l]["R"][1]]
+            if l > 0:
+                cols.append(raw[l - 1]["P"][1])
+            allc = torch.cat(cols).long()
+            out = allc[(allc < lo) | (allc >= hi)]
+            ghosts.append(torch.unique(out))           # sorted
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, [g.cpu().numpy() for g in ghosts], group=group)
+        for l in range(self.n_dist):
+            d = _DLevel()
+            lo, hi = self.bounds[l][self.rank], self.bounds[l][self.rank + 1]
+            d.lo, d.hi, d.n_own = lo, hi, hi - lo
+            d.ghost = ghosts[l]
+            d.n_tot = d.n_own + int(d.ghost.numel())
+            d.A = self._localise(raw[l]["A"], d, d.n_own)
+            nxt_rows = self.bounds[l + 1][self.rank + 1] - self.bounds[l + 1][self.rank]
+            d.R = self._localise(raw[l]["R"], d, nxt_rows)
+            d.P_raw = raw[l]["P"]
+            # exchange plan: recv segments are contiguous (ghosts sorted, owners contiguous)
+            gb = torch.tensor(self.bounds[l], device=d.ghost.device)
+            owner = torch.searchsorted(gb, d.ghost, right=True) - 1
+            d.recv = []
+            for q in torch.unique(owner).tolist():
+                idx = torch.nonzero(owner == q).flatten()
+                d.recv.append((int(q), d.n_own + int(idx[0]), int(idx.numel())))
+            d.send = []
+            for q in range(self.world):
+                if q == self.rank:
+                    continue
+                want = gathered[q][l]
+                mine = want[(want >= lo) & (want < hi)] - lo
+                if mine.size:
+                    d.send.append((q, torch.from_numpy(mine.astype(np.int32)).to(self.device),
+                                   torch.empty(mine.size, dtype=F64, device=self.device)))
+            for name in ("x", "b", "r", "tmp"):
+                setattr(d, name, torch.zeros(d.n_tot, dtype=F64, device=self.device))
+            self.dl.append(d)
+        # P of level l acts on level l+1 vectors: distributed layout or the full replicated vector
+        for l in range(self.n_dist):
+            d = self.dl[l]
+            ncoarse = full.levels[l + 1].n
+            if l + 1 < self.n_dist:
+                d.P = self._localise(d.P_raw, self.dl[l + 1], d.n_own)
+            else:
+                rp, ci, va = d.P_raw
+                d.P = DeviceCSR(rp, ci.contiguous(), va.contiguous(), (d.n_own, ncoarse))
+            del d.P_raw
+        # ---- all-gather plumbing for the first replicated level ----------------------------------
+        L = self.n_dist
+        cb = self.bounds[L]
+        self.ag_max = max(cb[p + 1] - cb[p] for p in range(self.world))
+        self.ag_send = torch.zeros(self.ag_max, dtype=F64, device=self.device)
+        self.ag_recv = torch.zeros(self.ag_max * self.world, dtype=F64, device=self.device)
+        idx = np.concatenate([np.arange(cb[p + 1] - cb[p]) + p * self.ag_max for p in range(self.world)])
+        self.ag_index = torch.from_numpy(idx.astype(np.int32)).to(self.device)
+        self.ag_rows = cb[self.rank + 1] - cb[self.rank]
+        self.partials = torch.empty(max(1024, self.ops.partials_count(self.dl[0].n_own)), dtype=F64,
+                                    device=self.device)
+        self.norm2 = torch.zeros(1, dtype=F64, device=self.device)
+
+    # ------------------------------------------------------------------------------------------
+    @classmethod
+    def from_problem(cls, A, transfers, device, ops_mod=None, **kw):
+        from .hierarchy import Hierarchy
+        return cls(Hierarchy(A, transfers, device, ops_mod=ops_mod), device, ops_mod=ops_mod, **kw)
+
+    @staticmethod
+    def _anchors(R):
+        """anchor[c] = column (fine row) of the largest entry of row c of R = P^T."""
+        n = R.shape[0]
+        counts = (R.rowptr[1:] - R.rowptr[:-1]).long()
+        rows = torch.repeat_interleave(torch.arange(n, device=R.vals.device), counts)
+        # largest value per row, then the first column attaining it
+        mx = torch.full((n,), -math.inf, dtype=F64, device=R.vals.device)
+        mx = mx.scatter_reduce(0, rows, R.vals, reduce="amax", include_self=True)
+        cand = torch.where(R.vals >= mx[rows], R.colidx.long(), torch.full_like(rows, 2 ** 62))
+        anchor = torch.full((n,), 2 ** 62, dtype=torch.long, device=R.vals.device)
+        anchor = anchor.scatter_reduce(0, rows, cand, reduce="amin", include_self=True)
+        anchor = torch.where(anchor == 2 ** 62, torch.zeros_like(anchor), anchor)   # empty rows
+        return anchor
+
+    def _localise(self, raw, d, nrows):
+        """Global column ids -> level layout [owned | ghosts]; entry order is preserved."""
+        rp, ci, va = raw
+        c = ci.long()
+        owned = (c >= d.lo) & (c < d.hi)
+        gpos = torch.searchsorted(d.ghost, c.clamp(min=0))
+        gpos = gpos.clamp(max=max(int(d.ghost.numel()) - 1, 0))
+        local = torch.where(owned, c - d.lo, d.n_own + gpos)
+        return DeviceCSR(rp.contiguous(), local.to(I32).contiguous(), va.contiguous(), (nrows, d.n_tot))
+
+    # ---- communication -----------------------------------------------------------------------------
+    def exchange(self, d, vec):
+        """Fill the ghost segment of `vec` (layout of level d) from the owning ranks."""
+        if not d.recv and not d.send:
+            return
+        p2p = []
+        for q, idx, buf in d.send:
+            self.ops.gather(idx, vec, buf)
+            p2p.append(dist.P2POp(dist.isend, buf, q, group=self.group))
+        for q, off, cnt in d.recv:
+            p2p.append(dist.P2POp(dist.irecv, vec[off:off + cnt], q, group=self.group))
+        for req in dist.batch_isend_irecv(p2p):
+            req.wait()
+
+    def set_rhs(self, rhs):
+        d = self.dl[0]
+        full = torch.from_numpy(np.ascontiguousarray(np.asarray(rhs, dtype=np.float64).reshape(-1)))
+        d.b[:d.n_own].copy_(full[d.lo:d.hi])
+        d.b[d.n_own:].zero_()
+
+    def set_x(self, x):
+        d = self.dl[0]
+        full = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1)))
+        d.x[:d.n_own].copy_(full[d.lo:d.hi])
+
+    def gather_solution(self):
+        """Full fine-level iterate on every rank (host array); test / output helper."""
+        d = self.dl[0]
+        parts = [None] * self.world
+        dist.all_gather_object(parts, d.x[:d.n_own].cpu().numpy(), group=self.group)
+        return np.concatenate(parts)
+
+    # ---- the cycle ---------------------------------------------------------------------------------------
+    def _smooth(self, d, steps, omega):
+        o = self.ops
+        for _ in range(steps):
+            self.exchange(d, d.x)
+            o.csr_jacobi(d.A, d.x, d.b, omega, d.tmp)
+            d.x, d.tmp = d.tmp, d.x
+
+    def cycle(self, smoother, steps, omega=1.0, l=0):
+        if smoother != "Jacobi":
+            raise ValueError("the distributed V-cycle supports the Jacobi smoother only "
+                             "(lexicographic Gauss-Seidel is sequential across ranks)")
+        o = self.ops
+        d = self.dl[l]
+        self._smooth(d, steps, omega)
+        self.exchange(d, d.x)
+        o.csr_residual_norm2(d.A, d.x, d.b, d.r, None, None)
+        self.exchange(d, d.r)
+        if l + 1 < self.n_dist:
+            nxt = self.dl[l + 1]
+            o.csr_spmv(d.R, d.r, nxt.b[:nxt.n_own], 1.0, 0.0)
+            o.zero(nxt.x)
+            self.cycle(smoother, steps, omega, l + 1)
+            self.exchange(nxt, nxt.x)
+            o.csr_spmv(d.P, nxt.x, d.x[:d.n_own], 1.0, 1.0)
+        else:
+            fl = self.full.levels[l + 1]
+            o.csr_spmv(d.R, d.r, self.ag_send[:self.ag_rows], 1.0, 0.0)
+            dist.all_gather_into_tensor(self.ag_recv, self.ag_send, group=self.group)
+            o.gather(self.ag_index, self.ag_recv, fl.b)
+            if l + 2 == len(self.full.levels):
+                self.full.coarse_solve()
+            else:
+                o.zero(fl.x)
+                self.full.cycle(smoother, steps, omega, l=l + 1)
+            o.csr_spmv(d.P, fl.x, d.x[:d.n_own], 1.0, 1.0)
+        self._smooth(d, steps, omega)
+
+    def residual_norm(self):
+        """||b - A x||_2 over all ranks: local fused sum of squares + all-reduce of 8 bytes."""
+        d = self.dl[0]
+        self.exchange(d, d.x)
+        self.ops.csr_residual_norm2(d.A, d.x, d.b, d.r, self.partials, self.norm2)
+        dist.all_reduce(self.norm2, op=dist.ReduceOp.SUM, group=self.group)
+        return math.sqrt(self.norm2.item())
+
+    def make_step(self, smoother, steps, omega, graph=False):
+        # RCCL point-to-point inside a captured hipGraph is left for a later round: eager launches
+        def step():
+            self.cycle(smoother, steps, omega)
+        return step
+
+    # what bench.py reports the roofline on
+    @property
+    def local_hierarchy(self):
+        return self.full
+
+    @property
+    def fine_local_matrix(self):
+        return self.dl[0].A
+
+    @property
+    def fine_local_rows(self):
+        return self.dl[0].n_own

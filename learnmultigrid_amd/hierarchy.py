@@ -127,7 +127,11 @@ class Level:
 class Hierarchy:
     """levels[0] is the fine grid; transfers[l] (n_l x n_{l+1}) prolongates level l+1 -> l."""
 
-    def __init__(self, A, transfers, device, coarse_refine=1, verbose=False):
+    def __init__(self, A, transfers, device, coarse_refine=1, verbose=False, ops_mod=None):
+        # `ops_mod` exists for the CPU-only host-logic tests (a test shim stands in for the
+        # HIP kernels); the product always runs with learnmultigrid_amd.ops.
+        self.ops = ops if ops_mod is None else ops_mod
+        ops_ = self.ops
         self.device = torch.device(device)
         self.coarse_refine = int(coarse_refine)
         self.verbose = verbose
@@ -151,12 +155,12 @@ class Hierarchy:
             Rh.sort_indices()
             lev.P = DeviceCSR.from_scipy(Ph, self.device)
             lev.R = DeviceCSR.from_scipy(Rh, self.device)
-            lev.plan_RA = ops.SpGEMMPlan(lev.R, lev.A)
+            lev.plan_RA = ops_.SpGEMMPlan(lev.R, lev.A)
             lev.RA = lev.plan_RA.numeric(lev.R, lev.A)
-            lev.plan_RAP = ops.SpGEMMPlan(lev.RA, lev.P)
+            lev.plan_RAP = ops_.SpGEMMPlan(lev.RA, lev.P)
             Ac = lev.plan_RAP.numeric(lev.RA, lev.P)
             self.levels.append(Level(Ac))
-        self.partials = torch.empty(ops.partials_count(self.levels[0].n), dtype=F64, device=self.device)
+        self.partials = torch.empty(ops_.partials_count(self.levels[0].n), dtype=F64, device=self.device)
         self.outer_r = torch.zeros(self.levels[0].n, dtype=F64, device=self.device)
         self.norm2 = torch.zeros(1, dtype=F64, device=self.device)
         self._factor_coarsest()
@@ -195,7 +199,7 @@ class Hierarchy:
                 lev.host_pattern = (lev.A.rowptr.cpu().numpy(), lev.A.colidx.cpu().numpy())
             rp, ci = lev.host_pattern
             pat = sp.csr_matrix((np.ones(ci.size, dtype=np.int8), ci, rp), shape=lev.A.shape)
-            lev.gs_sched[kind] = ops.build_gs_schedule(pat, kind, self.device)
+            lev.gs_sched[kind] = self.ops.build_gs_schedule(pat, kind, self.device)
         return lev.gs_sched[kind]
 
     # ------------------------------------------------------------------ solve ----------
@@ -204,21 +208,21 @@ class Hierarchy:
         if steps <= 0:
             return
         if smoother == "GaussSeidel":
-            ops.csr_gs_schedule(lev.A, lev.x, lev.b, self.gs_schedule(l, gs_mode), steps)
+            self.ops.csr_gs_schedule(lev.A, lev.x, lev.b, self.gs_schedule(l, gs_mode), steps)
         elif smoother == "Jacobi":
             for _ in range(steps):
-                ops.csr_jacobi(lev.A, lev.x, lev.b, omega, lev.tmp)
+                self.ops.csr_jacobi(lev.A, lev.x, lev.b, omega, lev.tmp)
                 lev.x, lev.tmp = lev.tmp, lev.x
         else:
             raise ValueError("unknown smoother %r" % (smoother,))
 
     def coarse_solve(self):
         lev = self.levels[-1]
-        ops.dense_gemv(self.coarse_inv, lev.b, lev.x)
+        self.ops.dense_gemv(self.coarse_inv, lev.b, lev.x)
         for _ in range(self.coarse_refine):
-            ops.csr_residual_norm2(lev.A, lev.x, lev.b, lev.r, None, None)
-            ops.dense_gemv(self.coarse_inv, lev.r, lev.tmp)
-            ops.axpby(1.0, lev.tmp, 1.0, lev.x)
+            self.ops.csr_residual_norm2(lev.A, lev.x, lev.b, lev.r, None, None)
+            self.ops.dense_gemv(self.coarse_inv, lev.r, lev.tmp)
+            self.ops.axpby(1.0, lev.tmp, 1.0, lev.x)
 
     def cycle(self, smoother, steps, omega=1.0, gs_mode="lexicographic", l=0, depth=None,
               after_presmooth=None):
@@ -229,20 +233,20 @@ class Hierarchy:
         self.smooth(l, smoother, steps, omega, gs_mode)                       # :88
         if after_presmooth is not None:
             after_presmooth(lev.x)
-        ops.csr_residual_norm2(lev.A, lev.x, lev.b, lev.r, None, None)        # :90
-        ops.csr_spmv(lev.R, lev.r, nxt.b, 1.0, 0.0)                           # :93
+        self.ops.csr_residual_norm2(lev.A, lev.x, lev.b, lev.r, None, None)        # :90
+        self.ops.csr_spmv(lev.R, lev.r, nxt.b, 1.0, 0.0)                           # :93
         if l + 1 == last:
             self.coarse_solve()                                               # :106
         else:
-            ops.zero(nxt.x)                                                   # :103
+            self.ops.zero(nxt.x)                                                   # :103
             self.cycle(smoother, steps, omega, gs_mode, l + 1, depth)
-        ops.csr_spmv(lev.P, nxt.x, lev.x, 1.0, 1.0)                           # :115
+        self.ops.csr_spmv(lev.P, nxt.x, lev.x, 1.0, 1.0)                           # :115
         self.smooth(l, smoother, steps, omega, gs_mode)                       # :121
 
     def residual_norm(self, want_vector=True):
         """||b - A x||_2 on the fine level (Multigrid.py:62-63); one 8-byte D2H copy."""
         lev = self.levels[0]
-        ops.csr_residual_norm2(lev.A, lev.x, lev.b, self.outer_r if want_vector else None,
+        self.ops.csr_residual_norm2(lev.A, lev.x, lev.b, self.outer_r if want_vector else None,
                                self.partials, self.norm2)
         return math.sqrt(self.norm2.item())
 
@@ -255,7 +259,7 @@ class Hierarchy:
                 for l in range(len(self.levels) - 1):
                     self.gs_schedule(l, gs_mode)            # host work must not happen in capture
             before = [(lev.x, lev.tmp) for lev in self.levels]
-            g = ops.CapturedGraph()
+            g = self.ops.CapturedGraph()
             with g:
                 self.cycle(smoother, steps, omega, gs_mode)
             after = [(lev.x, lev.tmp) for lev in self.levels]

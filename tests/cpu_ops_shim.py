@@ -1,0 +1,101 @@
+"""TEST-ONLY stand-in for learnmultigrid_amd.ops on CPU tensors.
+
+It lets the -m "not gpu" suite exercise the HOST logic that sits above the kernels
+(hierarchy recursion, row-block partitioning, ghost layouts, halo plans, collectives over
+gloo) by routing every kernel call to the CPU oracle.  It lives under tests/ on purpose:
+the product package never imports it and has no CPU path.
+"""
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from learnmultigrid_amd.ops import DeviceCSR, F64, I32   # pure-torch container, device agnostic
+from oracle import kernels as K
+
+
+def _np(t):
+    return t.numpy()
+
+
+def _sp(A):
+    return sp.csr_matrix((_np(A.vals), _np(A.colidx), _np(A.rowptr)), shape=A.shape)
+
+
+def partials_count(n):
+    return max(1024, (n + 255) // 256)
+
+
+def _raw(A):
+    """Raw CSR arrays in STORAGE order (no canonicalisation: the local matrices of the
+    distributed solver keep the global entry order after their columns are renumbered)."""
+    return A.shape[0], _np(A.rowptr), _np(A.colidx), _np(A.vals)
+
+
+def csr_residual_norm2(A, x, b, r, partials, norm2):
+    n, rp, ci, va = _raw(A)
+    rr = np.empty(n)
+    n2 = K.lib().orc_csr_residual(n, rp, ci, va, np.ascontiguousarray(_np(x)),
+                                  np.ascontiguousarray(_np(b)[:n]), rr)
+    if r is not None:
+        _np(r)[:n] = rr
+    if norm2 is not None:
+        _np(norm2)[0] = n2
+
+
+def csr_jacobi(A, x_in, b, omega, x_out):
+    # rectangular local matrices (owned rows x [owned | ghosts]): the diagonal is column == row
+    n, rp, ci, va = _raw(A)
+    out = np.empty(n)
+    K.lib().orc_csr_jacobi(n, rp, ci, va, np.ascontiguousarray(_np(x_in)),
+                           np.ascontiguousarray(_np(b)[:n]), float(omega), out)
+    _np(x_out)[:n] = out
+
+
+def csr_spmv(A, x, y, alpha=1.0, beta=0.0):
+    n, rp, ci, va = _raw(A)
+    out = np.ascontiguousarray(_np(y)[:n]).copy()
+    K.lib().orc_csr_spmv(n, rp, ci, va, np.ascontiguousarray(_np(x)), out, float(alpha), float(beta))
+    _np(y)[:n] = out
+
+
+def axpby(alpha, x, beta, y):
+    yy = _np(y)
+    yy[:] = alpha * _np(x) if beta == 0.0 else alpha * _np(x) + beta * yy
+
+
+def copy(src, dst):
+    dst.copy_(src)
+
+
+def zero(x):
+    x.zero_()
+
+
+def gather(idx, x, buf):
+    _np(buf)[: idx.numel()] = _np(x)[_np(idx)]
+
+
+def scatter(idx, buf, x):
+    _np(x)[_np(idx)] = _np(buf)[: idx.numel()]
+
+
+def dense_gemv(M, x, y):
+    _np(y)[:] = K.dense_gemv(_np(M), _np(x))
+
+
+class SpGEMMPlan:
+    def __init__(self, A, B):
+        self.shape = (A.shape[0], B.shape[1])
+
+    def numeric(self, A, B, out=None):
+        C = sp.csr_matrix(_sp(A) @ _sp(B))
+        C.sort_indices()
+        new = DeviceCSR.from_scipy(C, "cpu")
+        if out is not None:
+            out.vals.copy_(new.vals)
+            return out
+        return new
+
+
+def build_gs_schedule(*a, **k):
+    raise NotImplementedError("Gauss-Seidel schedules are exercised by the GPU tests")

@@ -1,0 +1,55 @@
+"""Distributed V-cycle with the real HIP kernels and RCCL, as far as ONE GPU allows:
+a world_size-1 "nccl" group drives the partitioned code path (local rectangular matrices,
+ghost layout, all_gather of the replicated level, all-reduced norm).  The multi-rank
+logic itself is covered by tests/test_dist_cpu.py (gloo, world 2 and 3)."""
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_world1_nccl_path_matches_single_gpu_bitwise():
+    import torch.distributed as dist
+    from learnmultigrid_amd import problems as P
+    from learnmultigrid_amd.dist import DistributedVCycle
+    from learnmultigrid_amd.hierarchy import Hierarchy
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        m, levels = 256, 5
+        A, rhs = P.poisson_2d_structured(m)
+        hier = P.geometric_hierarchy_2d(m + 1, levels)
+        D = DistributedVCycle.from_problem(A, hier, "cuda:0", grid_side=m + 1, replicate_below=10000)
+        assert D.n_dist == 2
+        D.set_rhs(rhs)
+        with torch.cuda.stream(D.stream):
+            norms = [D.residual_norm()]
+            for _ in range(4):
+                D.cycle("Jacobi", 3, 0.8)
+                norms.append(D.residual_norm())
+            x = D.dl[0].x[:D.dl[0].n_own].cpu().numpy()
+        H = Hierarchy(A, hier, "cuda:0")
+        H.levels[0].b.copy_(torch.from_numpy(rhs.ravel().copy()).to("cuda:0"))
+        with torch.cuda.stream(H.stream):
+            ref = [H.residual_norm()]
+            for _ in range(4):
+                H.cycle("Jacobi", 3, 0.8)
+                ref.append(H.residual_norm())
+            xr = H.levels[0].x.cpu().numpy()
+        assert np.array_equal(x, xr)
+        assert np.allclose(norms, ref, rtol=1e-13, atol=0)
+        assert norms[-1] < 1e-3 * norms[0]
+    finally:
+        dist.destroy_process_group()

@@ -215,7 +215,8 @@ def main():
                                   % (m, m, n, nnz, levels, nu, nu, args.omega),
                       "mode": args.mode, "step": "one full V-cycle" if args.mode == "vcycle"
                       else "1 Jacobi sweep + 1 residual on the fine level",
-                      "fine_sweeps_per_step": sweeps_per_step, "hipgraph": not args.no_graph,
+                      "fine_sweeps_per_step": sweeps_per_step,
+                      "hipgraph": (not args.no_graph) and world == 1 and not force_dist and args.mode == "vcycle",
                       "level_sizes": [int(s) for s in P.level_sizes(m + 1, levels)],
                       "partition": "row blocks of grid lines over %d rank(s)" % world,
                       "sweep_rpt": ops.tune_get("sweep_rpt")},

@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--omega", type=float, default=0.8)
     ap.add_argument("--mode", default="vcycle", choices=["vcycle", "sweep"])
     ap.add_argument("--no-graph", action="store_true", help="launch kernels from Python instead of replaying a hipGraph")
-    ap.add_argument("--rpt", type=int, default=0, help="sweep kernel rows/thread (0 = library default)")
+    ap.add_argument("--variant", type=int, default=-1, help="sweep kernel tile variant (-1 = library default)")
     ap.add_argument("--cpu-cycles", type=int, default=2, help="V-cycles timed by the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     return ap.parse_args()
@@ -108,8 +108,8 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    if args.rpt:
-        ops.tune_set("sweep_rpt", args.rpt)
+    if args.variant >= 0:
+        ops.tune_set("sweep_variant", args.variant)
 
     m, levels, nu = args.size, args.levels, args.nu
     A, rhs = P.poisson_2d_structured(m)
@@ -219,7 +219,7 @@ def main():
                       "hipgraph": (not args.no_graph) and world == 1 and not force_dist and args.mode == "vcycle",
                       "level_sizes": [int(s) for s in P.level_sizes(m + 1, levels)],
                       "partition": "row blocks of grid lines over %d rank(s)" % world,
-                      "sweep_rpt": ops.tune_get("sweep_rpt")},
+                      "sweep_variant": ops.tune_get("sweep_variant")},
            "setup_s": setup_s, "roofline": roofline}
     out["config"].update(out_extra)
     if cyc_bytes is not None:

@@ -1,0 +1,338 @@
+// Packed-CSR sweeps for gfx950: the same residual / Jacobi / SpMV arithmetic as sweep.hip on a
+// lossless re-encoding of the CSR matrix that moves fewer bytes through HBM.
+//
+// The sweeps are bandwidth-bound and sweep.hip already streams CSR at ~88 % of the copy
+// ceiling of the chip, so the only lever left is the byte count.  PCSR keeps the CSR entry
+// order (hence bit-identical row sums) and shrinks each stream where the data allows:
+//
+//   rowptr  (4 B/row)  -> rowlen  : uint8 per row + one int32 entry offset per 512-row tile
+//   colidx  (4 B/nnz)  -> col     : uint16 offset from the tile's smallest column (COL16)
+//                                   -- any matrix whose 512-row tiles span < 65536 columns,
+//                                   i.e. every banded / grid matrix -- else int32 (COL32)
+//   vals    (8 B/nnz)  -> val     : uint8 index into a dictionary of <= 256 distinct values
+//                                   (VAL8, dictionary held in LDS), uint16 index into <= 65536
+//                                   (VAL16, dictionary served by L2), else raw fp64 (VAL64)
+//
+// cfg#4 fine level (5-point, 3 distinct values): 88 B/DoF of CSR -> 40 B/DoF.  Matrices with
+// all-distinct values (jittered meshes, learned Q) still drop from 12 to 10 B/nnz.
+//
+// Kernel: persistent workgroups of 128 threads, 4 rows per thread (tile = 512 rows: one
+// scalar-load chain, one row-length scan and two barriers per 512 rows instead of per 128),
+// XCD-aware tile ownership, packed streams staged into LDS still packed (3 B/entry), rows
+// walked in storage order by lane t = row t (mod 128) so the x gathers of a wave stay
+// coalesced.  Same in-order, FMA-free accumulation as everywhere else.
+#include "lmg_common.hpp"
+
+namespace {
+
+enum { MODE_RESIDUAL = 0, MODE_JACOBI = 1, MODE_SPMV = 2 };
+enum { COL16 = 0, COL32 = 1 };
+enum { VAL8 = 0, VAL16 = 1, VAL64 = 2 };
+
+constexpr int kBlock = 128;
+constexpr int kRpt = 4;
+constexpr int kTileRows = kBlock * kRpt;   // 512
+
+struct PArgs {
+    int n;
+    int nnz;
+    int tiles;
+    int tiles_per_xcd;
+    int cap;                 // LDS capacity in entries (>= largest tile + alignment slack)
+    const int *tile_base;    // tiles + 1 entry offsets
+    const int *tile_colbase; // tiles
+    const unsigned char *rowlen;
+    const void *col;
+    const void *val;
+    const double *dict;
+    int ndict;
+    const double *x;
+    const double *b;
+    double *out;
+    double alpha, beta;
+    double *partial;
+};
+
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < LMG_WAVE; off <<= 1) {
+        const int u = __shfl_up(v, off, LMG_WAVE);
+        if (lane >= off) v += u;
+    }
+    return v;
+}
+
+template <int COLMODE> struct ColT { typedef unsigned short type; };
+template <> struct ColT<COL32> { typedef int type; };
+template <int VALMODE> struct ValT { typedef unsigned char type; };
+template <> struct ValT<VAL16> { typedef unsigned short type; };
+template <> struct ValT<VAL64> { typedef double type; };
+
+// copy the 16-byte-aligned byte window [lo16, hi) of a global array into LDS, 16 B per lane
+__device__ __forceinline__ void stage_bytes(const unsigned char *g, long lo16, long hi, unsigned char *s, int t)
+{
+    for (long off = lo16 + (long)t * 16; off < hi; off += (long)kBlock * 16)
+        *reinterpret_cast<v4u *>(s + (off - lo16)) = *reinterpret_cast<const v4u *>(g + off);
+}
+
+template <int MODE, int COLMODE, int VALMODE>
+__global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
+{
+    typedef typename ColT<COLMODE>::type col_t;
+    typedef typename ValT<VALMODE>::type val_t;
+    constexpr int CPER = 16 / (int)sizeof(col_t);   // entries per 16-byte chunk
+    constexpr int VPER = 16 / (int)sizeof(val_t);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: [dict (VAL8: 2048 B)] [col bytes] [val bytes] [scan: 8 ints] [red: 2 doubles]
+    double *s_dict = reinterpret_cast<double *>(smem);
+    const int dict_bytes = (VALMODE == VAL8) ? 2048 : 0;
+    const int col_bytes = ((a.cap * (int)sizeof(col_t) + 15) & ~15) + 16;
+    const int val_bytes = ((a.cap * (int)sizeof(val_t) + 15) & ~15) + 16;
+    unsigned char *s_colb = smem + dict_bytes;
+    unsigned char *s_valb = s_colb + col_bytes;
+    int *s_scan = reinterpret_cast<int *>(s_valb + val_bytes);
+    double *s_red = reinterpret_cast<double *>(s_scan + 8);
+    const col_t *s_col = reinterpret_cast<const col_t *>(s_colb);
+    const val_t *s_val = reinterpret_cast<const val_t *>(s_valb);
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int xcd = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3), nslots = (int)(gridDim.x >> 3);
+    const int t_begin = xcd * a.tiles_per_xcd;
+    const int t_end = min(a.tiles, t_begin + a.tiles_per_xcd);
+    if (t_begin + slot >= t_end) return;
+
+    if (VALMODE == VAL8) {
+        for (int i = t; i < 256; i += kBlock) s_dict[i] = i < a.ndict ? a.dict[i] : 0.0;
+    }
+
+    for (int tile = t_begin + slot; tile < t_end; tile += nslots) {
+        const int base = a.tile_base[tile];
+        const int end = a.tile_base[tile + 1];
+        const int cb0 = (COLMODE == COL16) ? a.tile_colbase[tile] : 0;
+        const int r0 = tile * kTileRows;
+
+        // ---- row lengths and their exclusive scan in row order (row = r0 + k*128 + t) ----
+        int len[kRpt], incl[kRpt];
+        double bv[kRpt];
+#pragma unroll
+        for (int k = 0; k < kRpt; ++k) {
+            const int row = r0 + k * kBlock + t;
+            len[k] = row < a.n ? (int)a.rowlen[row] : 0;
+            bv[k] = (MODE != MODE_SPMV && row < a.n) ? a.b[row] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < kRpt; ++k) {
+            incl[k] = wave_incl_scan_i(len[k], lane);
+            if (lane == 63) s_scan[k * 2 + wave] = incl[k];
+        }
+        // ---- stage the packed streams (still packed) ---------------------------------------
+        const int ac = base & ~(CPER - 1);          // first staged entry of each stream
+        const int av = base & ~(VPER - 1);
+        stage_bytes(reinterpret_cast<const unsigned char *>(a.col), (long)ac * sizeof(col_t),
+                    (long)end * sizeof(col_t), s_colb, t);
+        stage_bytes(reinterpret_cast<const unsigned char *>(a.val), (long)av * sizeof(val_t),
+                    (long)end * sizeof(val_t), s_valb, t);
+        __syncthreads();
+
+        // entry offset of each of this thread's 4 rows (k-major row order inside the tile)
+        int rs[kRpt];
+        {
+            int run = 0;
+#pragma unroll
+            for (int k = 0; k < kRpt; ++k) {
+                int before = run;
+                if (wave == 1) before += s_scan[k * 2];
+                run += s_scan[k * 2] + s_scan[k * 2 + 1];
+                rs[k] = base + before + incl[k] - len[k];
+            }
+        }
+        // walk the 4 rows TOGETHER, entry j of each per step: the 4 gathers of a step are
+        // independent, so one L2 round trip serves 4 rows (each row still accumulates its own
+        // entries in storage order).  Inactive slots read the tile's first entry (valid).
+        double acc[kRpt], diag[kRpt], xi[kRpt];
+        int maxlen = 0;
+#pragma unroll
+        for (int k = 0; k < kRpt; ++k) {
+            acc[k] = 0.0;
+            diag[k] = 0.0;
+            xi[k] = 0.0;
+            maxlen = max(maxlen, len[k]);
+        }
+        for (int j = 0; j < maxlen; ++j) {
+            int c[kRpt];
+            double v[kRpt], xv[kRpt];
+#pragma unroll
+            for (int k = 0; k < kRpt; ++k) {
+                const int p = (j < len[k]) ? rs[k] + j : base;
+                c[k] = cb0 + (int)s_col[p - ac];
+                if constexpr (VALMODE == VAL8) v[k] = s_dict[s_val[p - av]];
+                else if constexpr (VALMODE == VAL16) v[k] = a.dict[s_val[p - av]];
+                else v[k] = s_val[p - av];
+            }
+#pragma unroll
+            for (int k = 0; k < kRpt; ++k) xv[k] = a.x[c[k]];
+#pragma unroll
+            for (int k = 0; k < kRpt; ++k) {
+                const bool act = j < len[k];
+                const double s2 = acc[k] + v[k] * xv[k];
+                acc[k] = act ? s2 : acc[k];
+                if (MODE == MODE_JACOBI) {
+                    const bool dg = act && (c[k] == r0 + k * kBlock + t);
+                    diag[k] = dg ? diag[k] + v[k] : diag[k];
+                    xi[k] = dg ? xv[k] : xi[k];
+                }
+            }
+        }
+        double local = 0.0;
+#pragma unroll
+        for (int k = 0; k < kRpt; ++k) {
+            const int row = r0 + k * kBlock + t;
+            if (row < a.n) {
+                if (MODE == MODE_RESIDUAL) {
+                    const double r = bv[k] - acc[k];
+                    if (a.out) a.out[row] = r;
+                    local += r * r;
+                } else if (MODE == MODE_JACOBI) {
+                    const double r = bv[k] - acc[k];
+                    if (diag[k] != 0.0) a.out[row] = xi[k] + a.alpha * ((1.0 / diag[k]) * r);
+                    else a.out[row] = a.x[row];
+                } else {
+                    double s = acc[k];
+                    if (a.alpha != 1.0) s = a.alpha * s;
+                    if (a.beta == 0.0) a.out[row] = s;
+                    else if (a.beta == 1.0) a.out[row] = a.out[row] + s;
+                    else a.out[row] = a.beta * a.out[row] + s;
+                }
+            }
+        }
+        if (MODE == MODE_RESIDUAL && a.partial != nullptr) {
+            const double tot = lmg_block_sum<kBlock>(local, s_red);
+            if (t == 0) a.partial[tile] = tot;
+        }
+        __syncthreads();          // LDS tiles, s_scan and s_red are reused by the next tile
+    }
+}
+
+__global__ void __launch_bounds__(1024) pcsr_reduce_partials_kernel(const double *partial, int64_t count,
+                                                                    double *out)
+{
+    __shared__ double s_red[1024 / LMG_WAVE];
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    int64_t i = threadIdx.x;
+    for (; i + 3 * 1024 < count; i += 4 * 1024) {
+        v0 += partial[i];
+        v1 += partial[i + 1024];
+        v2 += partial[i + 2048];
+        v3 += partial[i + 3072];
+    }
+    for (; i < count; i += 1024) v0 += partial[i];
+    const double tot = lmg_block_sum<1024>((v0 + v1) + (v2 + v3), s_red);
+    if (threadIdx.x == 0) out[0] = tot;
+}
+
+constexpr int kMaxLds = 64 * 1024;
+
+int lds_bytes(int cap, int colmode, int valmode)
+{
+    const int cs = colmode == COL16 ? 2 : 4;
+    const int vs = valmode == VAL8 ? 1 : (valmode == VAL16 ? 2 : 8);
+    return (valmode == VAL8 ? 2048 : 0) + ((cap * cs + 15) & ~15) + 16 + ((cap * vs + 15) & ~15) + 16 + 32 + 16;
+}
+
+template <int MODE, int COLMODE, int VALMODE>
+int launch(PArgs a, hipStream_t st)
+{
+    const int lds = lds_bytes(a.cap, COLMODE, VALMODE);
+    if (lds > kMaxLds) return LMG_ERR_CAPACITY;
+    // persistent grid: exactly as many workgroups per CU as registers + LDS admit
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcsr_sweep_kernel<MODE, COLMODE, VALMODE>,
+                                                     kBlock, (size_t)lds) != hipSuccess || per_cu < 1)
+        per_cu = 4;
+    if (per_cu > 16) per_cu = 16;
+    int64_t grid = 256 * (int64_t)per_cu;
+    if (grid > (int64_t)a.tiles_per_xcd * 8) grid = (int64_t)a.tiles_per_xcd * 8;
+    hipLaunchKernelGGL((pcsr_sweep_kernel<MODE, COLMODE, VALMODE>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+template <int MODE>
+int dispatch(PArgs a, int colmode, int valmode, hipStream_t st)
+{
+    if (colmode == COL16) {
+        if (valmode == VAL8) return launch<MODE, COL16, VAL8>(a, st);
+        if (valmode == VAL16) return launch<MODE, COL16, VAL16>(a, st);
+        if (valmode == VAL64) return launch<MODE, COL16, VAL64>(a, st);
+    } else if (colmode == COL32) {
+        if (valmode == VAL8) return launch<MODE, COL32, VAL8>(a, st);
+        if (valmode == VAL16) return launch<MODE, COL32, VAL16>(a, st);
+        if (valmode == VAL64) return launch<MODE, COL32, VAL64>(a, st);
+    }
+    return LMG_ERR_ARG;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lmg_pcsr_tile_rows(void) { return kTileRows; }
+
+int lmg_pcsr_sweep(int mode, int64_t n, int64_t nnz, int32_t tile_cap, const int32_t *tile_base,
+                   const int32_t *tile_colbase, const uint8_t *rowlen, const void *col, int colmode,
+                   const void *val, int valmode, const double *dict, int32_t ndict, const double *x,
+                   const double *b, double *out, double alpha, double beta, double *partials,
+                   double *norm2, void *stream)
+{
+    if (n < 0 || nnz < 0 || n >= INT32_MAX || nnz >= INT32_MAX - 65536 || tile_cap < 0) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    if (!tile_base || !rowlen || (nnz > 0 && (!col || !val || !x))) return LMG_ERR_ARG;
+    if (colmode == COL16 && !tile_colbase) return LMG_ERR_ARG;
+    if (valmode != VAL64 && (!dict || ndict <= 0)) return LMG_ERR_ARG;
+    if ((valmode == VAL8 && ndict > 256) || (valmode == VAL16 && ndict > 65536)) return LMG_ERR_ARG;
+    if (!lmg_aligned16(col) || !lmg_aligned16(val)) return LMG_ERR_ALIGN;
+    if (mode == MODE_SPMV) {
+        if (!out || x == out) return LMG_ERR_ARG;
+    } else if (mode == MODE_JACOBI) {
+        if (!b || !out || x == out) return LMG_ERR_ARG;
+    } else if (mode == MODE_RESIDUAL) {
+        if (!b || (partials == nullptr) != (norm2 == nullptr) || (!out && !partials)) return LMG_ERR_ARG;
+    } else {
+        return LMG_ERR_ARG;
+    }
+    PArgs a;
+    a.n = (int)n;
+    a.nnz = (int)nnz;
+    a.tiles = (int)((n + kTileRows - 1) / kTileRows);
+    a.tiles_per_xcd = (a.tiles + 7) / 8;
+    a.cap = tile_cap + 32;
+    a.tile_base = tile_base;
+    a.tile_colbase = tile_colbase;
+    a.rowlen = rowlen;
+    a.col = col;
+    a.val = val;
+    a.dict = dict;
+    a.ndict = ndict;
+    a.x = x;
+    a.b = b;
+    a.out = out;
+    a.alpha = alpha;
+    a.beta = beta;
+    a.partial = (mode == MODE_RESIDUAL) ? partials : nullptr;
+    hipStream_t st = lmg_stream(stream);
+    int rc;
+    if (mode == MODE_RESIDUAL) rc = dispatch<MODE_RESIDUAL>(a, colmode, valmode, st);
+    else if (mode == MODE_JACOBI) rc = dispatch<MODE_JACOBI>(a, colmode, valmode, st);
+    else rc = dispatch<MODE_SPMV>(a, colmode, valmode, st);
+    if (rc != LMG_OK) return rc;
+    if (mode == MODE_RESIDUAL && partials) {
+        hipLaunchKernelGGL(pcsr_reduce_partials_kernel, dim3(1), dim3(1024), 0, st, partials, (int64_t)a.tiles, norm2);
+        LMG_CHECK_LAUNCH();
+    }
+    return LMG_OK;
+}
+
+}  // extern "C"

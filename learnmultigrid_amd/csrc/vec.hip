@@ -214,14 +214,14 @@ int lmg_device_count(void)
 int lmg_tune_set(const char *key, int value)
 {
     if (!key) return LMG_ERR_ARG;
-    if (strcmp(key, "sweep_rpt") == 0) return lmg_sweep_tune_set(value);
+    if (strcmp(key, "sweep_variant") == 0) return lmg_sweep_tune_set(value);
     return LMG_ERR_ARG;
 }
 
 int lmg_tune_get(const char *key)
 {
     if (!key) return LMG_ERR_ARG;
-    if (strcmp(key, "sweep_rpt") == 0) return lmg_sweep_tune_get();
+    if (strcmp(key, "sweep_variant") == 0) return lmg_sweep_tune_get();
     return LMG_ERR_ARG;
 }
 

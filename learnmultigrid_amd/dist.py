@@ -164,6 +164,10 @@ class DistributedVCycle:
                 rp, ci, va = d.P_raw
                 d.P = DeviceCSR(rp, ci.contiguous(), va.contiguous(), (d.n_own, ncoarse))
             del d.P_raw
+        if getattr(full, "use_packed", False):
+            for d in self.dl:
+                for M in (d.A, d.R, d.P):
+                    M.pack()
         # ---- all-gather plumbing for the first replicated level ----------------------------------
         L = self.n_dist
         cb = self.bounds[L]

@@ -127,7 +127,8 @@ class Level:
 class Hierarchy:
     """levels[0] is the fine grid; transfers[l] (n_l x n_{l+1}) prolongates level l+1 -> l."""
 
-    def __init__(self, A, transfers, device, coarse_refine=1, verbose=False, ops_mod=None):
+    def __init__(self, A, transfers, device, coarse_refine=1, verbose=False, ops_mod=None,
+                 use_packed=True):
         # `ops_mod` exists for the CPU-only host-logic tests (a test shim stands in for the
         # HIP kernels); the product always runs with learnmultigrid_amd.ops.
         self.ops = ops if ops_mod is None else ops_mod
@@ -160,6 +161,8 @@ class Hierarchy:
             lev.plan_RAP = ops_.SpGEMMPlan(lev.RA, lev.P)
             Ac = lev.plan_RAP.numeric(lev.RA, lev.P)
             self.levels.append(Level(Ac))
+        self.use_packed = bool(use_packed)
+        self._pack_all()
         self.partials = torch.empty(ops_.partials_count(self.levels[0].n), dtype=F64, device=self.device)
         self.outer_r = torch.zeros(self.levels[0].n, dtype=F64, device=self.device)
         self.norm2 = torch.zeros(1, dtype=F64, device=self.device)
@@ -170,6 +173,15 @@ class Hierarchy:
     @property
     def sizes(self):
         return [lev.n for lev in self.levels]
+
+    def _pack_all(self):
+        """Packed twins (lossless, fewer HBM bytes) of every operator the sweeps touch."""
+        if not self.use_packed:
+            return
+        for lev in self.levels:
+            for M in (lev.A, lev.P, lev.R):
+                if M is not None and hasattr(M, "pack"):
+                    M.pack()
 
     def _factor_coarsest(self):
         Ac = self.levels[-1].A
@@ -189,6 +201,9 @@ class Hierarchy:
             lev = self.levels[l]
             lev.plan_RA.numeric(lev.R, lev.A, out=lev.RA)
             lev.plan_RAP.numeric(lev.RA, lev.P, out=self.levels[l + 1].A)
+        for lev in self.levels:
+            lev.A.invalidate_packed()
+        self._pack_all()
         self._factor_coarsest()
         self._graphs = {}
 

@@ -37,7 +37,7 @@ def _vec_ok(*ts):
 class DeviceCSR:
     """CSR matrix resident in HBM: int32 rowptr[n+1], int32 colidx[nnz], fp64 vals[nnz]."""
 
-    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz")
+    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz", "packed")
 
     def __init__(self, rowptr, colidx, vals, shape):
         if rowptr.dtype != I32 or colidx.dtype != I32 or vals.dtype != F64:
@@ -47,6 +47,16 @@ class DeviceCSR:
         self.rowptr, self.colidx, self.vals = rowptr.contiguous(), colidx.contiguous(), vals.contiguous()
         self.shape = (int(shape[0]), int(shape[1]))
         self.nnz = int(vals.numel())
+        self.packed = None           # PackedCSR twin used by the sweeps once pack() was called
+
+    def pack(self):
+        """Build (once) the packed twin the sweep kernels prefer; keeps the CSR arrays."""
+        if self.packed is None and self.vals.is_cuda:
+            self.packed = PackedCSR.from_csr(self)
+        return self.packed
+
+    def invalidate_packed(self):
+        self.packed = None
 
     @classmethod
     def from_scipy(cls, A, device, canonical=True):
@@ -76,6 +86,100 @@ class DeviceCSR:
         return 12 * self.nnz + 4 * (self.shape[0] + 1)
 
 
+class PackedCSR:
+    """Lossless packed twin of a DeviceCSR for lmg_pcsr_sweep (see include/lmg.h):
+    uint8 row lengths, uint16 tile-relative columns when every 512-row tile spans < 65536
+    columns, and a value dictionary (uint8 / uint16 indices) when the matrix has few
+    distinct values -- compared BITWISE, so -0.0 / NaN payloads survive.  Built with torch
+    ops at setup (format conversion, like SciPy's csc -> csr); the sweeps are the HIP kernel."""
+
+    __slots__ = ("n", "nnz", "shape", "tile_cap", "tile_base", "tile_colbase", "rowlen", "col",
+                 "colmode", "val", "valmode", "dict", "ndict", "bytes_")
+
+    @staticmethod
+    def _padded(t):
+        raw = t.contiguous().view(torch.uint8)
+        out = torch.zeros(((raw.numel() + 15) // 16) * 16 + 16, dtype=torch.uint8, device=t.device)
+        out[: raw.numel()] = raw
+        return out
+
+    @classmethod
+    def from_csr(cls, A):
+        n, nnz = A.shape[0], A.nnz
+        if n == 0 or nnz == 0:
+            return None
+        dev = A.vals.device
+        T = int(_lib.lib().lmg_pcsr_tile_rows())
+        rowlen = (A.rowptr[1:] - A.rowptr[:-1])
+        if int(rowlen.max()) > 255 or int(rowlen.min()) < 0:
+            return None
+        ntile = (n + T - 1) // T
+        tb = A.rowptr[0:n:T]
+        tile_base = torch.cat([tb, A.rowptr[n:n + 1]]).contiguous()
+        tile_nnz = tile_base[1:] - tile_base[:-1]
+        self = cls()
+        self.n, self.nnz, self.shape = n, nnz, A.shape
+        self.tile_cap = int(tile_nnz.max())
+        self.tile_base = tile_base
+        self.rowlen = rowlen.to(torch.uint8).contiguous()
+        tile_of_entry = torch.repeat_interleave(torch.arange(ntile, device=dev), tile_nnz.long())
+        big = torch.iinfo(torch.int32).max
+        cmin = torch.full((ntile,), big, dtype=I32, device=dev).scatter_reduce(
+            0, tile_of_entry, A.colidx, reduce="amin", include_self=True)
+        cmax = torch.zeros(ntile, dtype=I32, device=dev).scatter_reduce(
+            0, tile_of_entry, A.colidx, reduce="amax", include_self=True)
+        cmin = torch.where(tile_nnz > 0, cmin, torch.zeros_like(cmin))
+        if int((cmax - cmin).max()) < 65536:
+            self.colmode = 0
+            self.tile_colbase = cmin.contiguous()
+            rel = (A.colidx - cmin[tile_of_entry])
+            self.col = cls._padded(rel.to(torch.int16))          # wraps: read back as uint16
+        else:
+            self.colmode = 1
+            self.tile_colbase = cmin.contiguous()
+            self.col = cls._padded(A.colidx)
+        del tile_of_entry
+        bits = A.vals.view(torch.int64)
+        uniq = torch.unique(bits)
+        self.ndict = int(uniq.numel())
+        if self.ndict <= 256:
+            self.valmode = 0
+            self.val = cls._padded(torch.searchsorted(uniq, bits).to(torch.uint8))
+            self.dict = uniq.view(F64).contiguous()
+        elif self.ndict <= 65536:
+            self.valmode = 1
+            self.val = cls._padded(torch.searchsorted(uniq, bits).to(torch.int16))
+            self.dict = uniq.view(F64).contiguous()
+        else:
+            self.valmode = 2
+            self.val = cls._padded(A.vals)
+            self.dict = None
+            self.ndict = 0
+        self.bytes_ = (self.rowlen.numel() + 8 * ntile + nnz * ((2, 4)[self.colmode] + (1, 2, 8)[self.valmode]))
+        return self
+
+    def bytes(self):
+        return int(self.bytes_)
+
+
+_PACKED_ENABLED = True
+
+
+def set_packed_enabled(flag):
+    """Route csr_jacobi / csr_residual_norm2 / csr_spmv through the packed twin when one
+    exists (default) or always through the plain CSR kernels (A/B and parity tests)."""
+    global _PACKED_ENABLED
+    _PACKED_ENABLED = bool(flag)
+
+
+def _pcsr(mode, P, x, b, out, alpha, beta, partials, norm2):
+    rc = _lib.lib().lmg_pcsr_sweep(mode, P.n, P.nnz, P.tile_cap, _p(P.tile_base), _p(P.tile_colbase),
+                                   _p(P.rowlen), _p(P.col), P.colmode, _p(P.val), P.valmode,
+                                   _p(P.dict), P.ndict, _p(x), _p(b), _p(out), float(alpha), float(beta),
+                                   _p(partials), _p(norm2), _s())
+    return rc
+
+
 def partials_count(n):
     return int(_lib.lib().lmg_partials_count(int(n)))
 
@@ -92,6 +196,11 @@ def tune_get(key):
 def csr_residual_norm2(A, x, b, r, partials, norm2):
     """r = b - A x (r may be None), norm2[0] = sum r_i^2 (partials/norm2 may both be None)."""
     _vec_ok(x, b, r, partials, norm2)
+    if _PACKED_ENABLED and A.packed is not None:
+        rc = _pcsr(0, A.packed, x, b, r, 0.0, 0.0, partials, norm2)
+        if rc != -4:                                   # LMG_ERR_CAPACITY: tile too large for LDS
+            check(rc, "lmg_pcsr_sweep(residual)")
+            return
     check(_lib.lib().lmg_csr_residual_norm2(A.shape[0], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.vals),
                                             _p(x), _p(b), _p(r), _p(partials), _p(norm2), _s()),
           "lmg_csr_residual_norm2")
@@ -99,6 +208,11 @@ def csr_residual_norm2(A, x, b, r, partials, norm2):
 
 def csr_jacobi(A, x_in, b, omega, x_out):
     _vec_ok(x_in, b, x_out)
+    if _PACKED_ENABLED and A.packed is not None:
+        rc = _pcsr(1, A.packed, x_in, b, x_out, omega, 0.0, None, None)
+        if rc != -4:
+            check(rc, "lmg_pcsr_sweep(jacobi)")
+            return
     check(_lib.lib().lmg_csr_jacobi(A.shape[0], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.vals),
                                     _p(x_in), _p(b), float(omega), _p(x_out), _s()), "lmg_csr_jacobi")
 
@@ -107,6 +221,11 @@ def csr_spmv(A, x, y, alpha=1.0, beta=0.0):
     _vec_ok(x, y)
     if x.numel() != A.shape[1] or y.numel() != A.shape[0]:
         raise ValueError("spmv shape mismatch: A %s, x %d, y %d" % (A.shape, x.numel(), y.numel()))
+    if _PACKED_ENABLED and A.packed is not None:
+        rc = _pcsr(2, A.packed, x, None, y, alpha, beta, None, None)
+        if rc != -4:
+            check(rc, "lmg_pcsr_sweep(spmv)")
+            return
     check(_lib.lib().lmg_csr_spmv(A.shape[0], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.vals),
                                   _p(x), _p(y), float(alpha), float(beta), _s()), "lmg_csr_spmv")
 

@@ -73,11 +73,11 @@ SQUARE = ["poisson1d_1025", "poisson2d_65", "poisson2d_513", "ragged_1000", "rag
 ALL = SQUARE + ["prolong_65", "restrict_65", "l2like_restrict"]
 
 
-@pytest.fixture(params=[1, 2, 4], ids=lambda r: "rpt%d" % r)
+@pytest.fixture(params=list(range(24)), ids=lambda r: "variant%d" % r)
 def rpt(request):
-    ops.tune_set("sweep_rpt", request.param)
+    ops.tune_set("sweep_variant", request.param)
     yield request.param
-    ops.tune_set("sweep_rpt", 1)
+    ops.tune_set("sweep_variant", 0)
 
 
 @pytest.mark.parametrize("name", ALL)
@@ -360,3 +360,105 @@ def test_torch_custom_ops_registered():
     assert np.array_equal(r.cpu().numpy(), wr)
     y = torch.ops.lmg.csr_spmv(dA.rowptr, dA.colidx, dA.vals, A.shape[1], x)
     assert np.array_equal(y.cpu().numpy(), A @ x.cpu().numpy())
+
+
+# ---- packed CSR (lmg_pcsr_sweep): same results, bit for bit, in every encoding -------------------
+@functools.lru_cache(maxsize=None)
+def packed_case(name):
+    if name == "val8_col16_poisson2d_513":
+        return case("poisson2d_513")
+    if name == "val8_col16_prolong":
+        return case("prolong_65")
+    if name == "val8_col16_restrict":
+        return case("restrict_65")
+    if name == "val8_col16_poisson1d":
+        return case("poisson1d_1025")
+    if name == "val16_col16_ragged":
+        return case("ragged_1000")
+    if name == "val64_col16_jittered":
+        return K.as_csr(P.jittered_poisson_2d(300, seed=7)[0])
+    if name in ("val64_col32_random", "val16_col32_random"):
+        # (sp.random would build a permutation of n*n indices: sample coordinates directly)
+        n = 150000 if name.startswith("val64") else 120000
+        rng = np.random.default_rng(11)
+        k = 6 * n
+        r, c = rng.integers(0, n, k), rng.integers(0, n, k)
+        v = rng.standard_normal(k) if name.startswith("val64") else rng.integers(1, 3000, k).astype(np.float64)
+        A = sp.coo_matrix((v, (r, c)), shape=(n, n)).tocsr() + sp.identity(n) * 3.0
+        return K.as_csr(A)
+    if name == "galerkin_9pt":
+        A2, _ = P.poisson_2d_structured(256)
+        Pm = P.tensor_interpolator_2d(257)
+        return K.as_csr(sp.csr_matrix(Pm.T @ A2 @ Pm))
+    raise KeyError(name)
+
+
+PACKED = ["val8_col16_poisson2d_513", "val8_col16_prolong", "val8_col16_restrict", "val8_col16_poisson1d",
+          "val16_col16_ragged", "val64_col16_jittered", "val64_col32_random", "val16_col32_random",
+          "galerkin_9pt"]
+
+
+@pytest.mark.parametrize("name", PACKED)
+def test_packed_sweeps_bit_exact(name):
+    A = packed_case(name)
+    n, m = A.shape
+    rng = np.random.default_rng(21)
+    x, b, y0 = rng.standard_normal(m), rng.standard_normal(n), rng.standard_normal(n)
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    Pk = dA.pack()
+    assert Pk is not None
+    want_modes = {"val8": 0, "val16": 1, "val64": 2}
+    for key, vm in want_modes.items():
+        if name.startswith(key):
+            assert Pk.valmode == vm, (name, Pk.valmode, Pk.ndict)
+    if "_col16_" in name:
+        assert Pk.colmode == 0
+    if "_col32_" in name:
+        assert Pk.colmode == 1
+    assert Pk.bytes() < dA.bytes()
+    try:
+        ops.set_packed_enabled(True)
+        for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (-0.5, 2.0)):
+            y = dev(y0.copy())
+            ops.csr_spmv(dA, dev(x), y, alpha, beta)
+            assert np.array_equal(y.cpu().numpy(), K.spmv(A, x, y0, alpha, beta)), (name, alpha, beta)
+        if n == m:
+            r = torch.empty(n, dtype=torch.float64, device=DEV)
+            part = torch.empty(ops.partials_count(n), dtype=torch.float64, device=DEV)
+            n2 = torch.zeros(1, dtype=torch.float64, device=DEV)
+            ops.csr_residual_norm2(dA, dev(x), dev(b), r, part, n2)
+            wr, wn2 = K.residual(A, x, b)
+            assert np.array_equal(r.cpu().numpy(), wr)
+            assert abs(n2.item() - wn2) <= 1e-13 * wn2
+            n2b = torch.zeros(1, dtype=torch.float64, device=DEV)
+            ops.csr_residual_norm2(dA, dev(x), dev(b), None, part, n2b)
+            assert n2b.item() == n2.item()
+            for omega in (1.0, 0.8):
+                out = torch.empty(n, dtype=torch.float64, device=DEV)
+                ops.csr_jacobi(dA, dev(x), dev(b), omega, out)
+                assert np.array_equal(out.cpu().numpy(), K.jacobi(A, x, b, omega)), (name, omega)
+            # and the packed path really is a different kernel from the plain one
+            ops.set_packed_enabled(False)
+            out2 = torch.empty(n, dtype=torch.float64, device=DEV)
+            ops.csr_jacobi(dA, dev(x), dev(b), 0.8, out2)
+            assert torch.equal(out, out2)
+    finally:
+        ops.set_packed_enabled(True)
+
+
+def test_packing_is_refused_for_rows_longer_than_255_and_preserves_signed_zero():
+    A = case("ragged_longrow_6007")
+    assert ops.DeviceCSR.from_scipy(A, DEV).pack() is None
+    # -0.0 and +0.0 are different dictionary entries (bitwise dictionary)
+    M = sp.csr_matrix((np.array([0.0, -0.0, 1.0, 2.0]), np.array([0, 1, 0, 1]), np.array([0, 2, 4])), shape=(2, 2))
+    dM = ops.DeviceCSR(dev(M.indptr.astype(np.int32)), dev(M.indices.astype(np.int32)), dev(M.data), (2, 2))
+    Pk = dM.pack()
+    assert Pk.ndict == 4
+    x = np.array([-1.0, 1.0])
+    y = torch.empty(2, dtype=torch.float64, device=DEV)
+    ops.csr_spmv(dM, dev(x), y, 1.0, 0.0)
+    got = y.cpu().numpy()
+    want = K.lib()  # noqa: F841
+    ref = np.empty(2)
+    K.lib().orc_csr_matvec(2, M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data, x, ref)
+    assert np.array_equal(np.signbit(got), np.signbit(ref)) and np.array_equal(got, ref)

@@ -47,6 +47,7 @@ const char *lmg_status_string(int status);
 int lmg_device_count(void);
 
 /* Runtime tuning knobs (kernel variant selection; used by bench.py for A/B runs).
+ *   key "pcsr_ju"       : row entries per step of the packed sweeps (0 = auto, 1, 2, 3, 5).
  *   key "sweep_variant" : tile geometry of the sweep kernels, 0..23 (0 = default: chosen
  *                         per launch from the average row length).                     */
 int lmg_tune_set(const char *key, int value);
@@ -141,6 +142,10 @@ int lmg_scatter(int64_t n, const int32_t *d_idx, const double *d_buf, double *d_
  * `spsolve(A_coarse, res_coarse)` of Multigrid.py:106. */
 int lmg_dense_gemv(int64_t n, int64_t m, const double *d_M, const double *d_x, double *d_y,
                    void *stream);
+/* y_b = M_b x_b for nblocks dense bs x bs blocks stored one after the other (bs even):
+ * the strip solves of the banded block-elimination coarse solver (coarse.py). */
+int lmg_dense_gemv_blockdiag(int64_t nblocks, int64_t bs, const double *d_M, const double *d_x,
+                             double *d_y, void *stream);
 
 /* ---- Galerkin product (SpGEMM)  C = A * B -----------------------------------------
  * Replaces SciPy's csr_matmat behind `i.T @ A @ i` (Multigrid.py:97-98), evaluated as

@@ -41,6 +41,7 @@ SIGNATURES = {
     "lmg_gather": (_c.c_int, [_i64, _p, _p, _p, _p]),
     "lmg_scatter": (_c.c_int, [_i64, _p, _p, _p, _p]),
     "lmg_dense_gemv": (_c.c_int, [_i64, _i64, _p, _p, _p, _p]),
+    "lmg_dense_gemv_blockdiag": (_c.c_int, [_i64, _i64, _p, _p, _p, _p]),
     "lmg_spgemm_count": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p]),
     "lmg_spgemm_symbolic": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _i32, _p, _p]),
     "lmg_spgemm_numeric": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),

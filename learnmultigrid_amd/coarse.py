@@ -1,0 +1,228 @@
+"""Coarsest-level direct solve on the device (replaces `spsolve(A_coarse, res_coarse)`,
+learn_multigrid/solvers/Multigrid.py:106, which re-factorises with SuperLU in every cycle).
+
+Setup happens once; every application is a handful of HBM-bound GEMV / SpMV launches
+(graph-capturable, no host round trip).  Two strategies:
+
+* `DenseInverse` -- A^-1 as one dense fp64 matrix applied by lmg_dense_gemv: 8 n^2 bytes per
+  application (129^2 unknowns: 2.2 GB, ~0.55 ms on MI355X).  Used for small or non-banded
+  operators.
+
+* `BandedBlockSolver` -- for operators with half-bandwidth w << n in their natural ordering
+  (every Galerkin operator of a row-major grid: w = side + 1).  The unknowns are cut into k
+  strips separated by k-1 separator blocks of >= w unknowns, so strips only couple through
+  separators (one-level nested dissection in the given ordering, EXACT block elimination):
+
+        [ A_II  A_IS ] [x_I]   [b_I]        A_II = blockdiag(strip_0 .. strip_{k-1})
+        [ A_SI  A_SS ] [x_S] = [b_S]        S    = A_SS - A_SI A_II^-1 A_IS
+
+        y_I = A_II^-1 b_I ;  x_S = S^-1 (b_S - A_SI y_I) ;  x_I = A_II^-1 (b_I - A_IS x_S)
+
+  Dense storage: k strip inverses (s x s) + S^-1, i.e. about n^2/k + ((k-1)w)^2 doubles
+  instead of n^2: 129^2 unknowns, k = 16 -> 2 x 108 MB + 30 MB per application instead of
+  2.2 GB.  Pivoting happens inside the strips only (fine for the M-matrix-like Galerkin
+  operators); `refine` steps of iterative refinement against the true sparse operator are
+  applied by the caller and make the result as accurate as a pivoted factorisation.
+"""
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from .ops import DeviceCSR, F64, I32
+
+MAX_DENSE = 46000          # 46000^2 * 8 B = 17 GB of the 288 GB HBM
+_INV_LEAF = 512
+
+
+def csr_to_dense(A):
+    n, m = A.shape
+    dense = torch.zeros((n, m), dtype=F64, device=A.device)
+    rows = torch.repeat_interleave(torch.arange(n, device=A.device), (A.rowptr[1:] - A.rowptr[:-1]).long())
+    dense.index_put_((rows, A.colidx.long()), A.vals, accumulate=True)
+    return dense
+
+
+def _inv_schur(A):
+    """Recursive 2x2 Schur-complement inversion: only small leaf inversions and plain
+    rocBLAS GEMMs (torch.matmul).  No pivoting across blocks; dense_inverse() verifies."""
+    n = A.shape[0]
+    if n <= _INV_LEAF:
+        return torch.linalg.inv(A)
+    k = n // 2
+    A11, A12, A21, A22 = A[:k, :k], A[:k, k:], A[k:, :k], A[k:, k:]
+    I11 = _inv_schur(A11.contiguous())
+    T = I11 @ A12
+    IS = _inv_schur((A22 - A21 @ T).contiguous())
+    W = IS @ (A21 @ I11)
+    out = torch.empty_like(A)
+    out[k:, k:] = IS
+    out[k:, :k] = -W
+    out[:k, k:] = -(T @ IS)
+    out[:k, :k] = I11 + T @ W
+    return out
+
+
+def dense_inverse(dense, polish=2, tol=1e-9):
+    """A^-1 on the device (SETUP phase).  rocSOLVER's getri/getrs path (torch.linalg.inv) is
+    used while it works, but it cannot get its trsm workspace for n ~ 16 000 on this stack
+    (HIPBLAS_STATUS_ALLOC_FAILED); then: block Schur recursion on GEMMs, `polish`
+    Newton-Schulz steps M <- M (2I - A M), verification max|I - A M| < tol, and as a last
+    resort a pure Newton-Schulz iteration from A^T/(|A|_1 |A|_inf), which converges for
+    every nonsingular A.  Raises if the operator is numerically singular."""
+    n = dense.shape[0]
+    eye = torch.eye(n, dtype=F64, device=dense.device)
+
+    def defect(M):
+        return float((eye - dense @ M).abs().max())
+
+    try:
+        M = torch.linalg.inv(dense)
+        steps = 0
+    except RuntimeError:
+        M = _inv_schur(dense)
+        steps = polish
+    ok = bool(torch.isfinite(M).all())
+    if ok:
+        for _ in range(steps):
+            M = M @ (2.0 * eye - dense @ M)
+        ok = bool(torch.isfinite(M).all()) and defect(M) < tol
+    if not ok:
+        M = dense.t().contiguous() / (dense.abs().sum(0).max() * dense.abs().sum(1).max())
+        for _ in range(200):
+            M = M @ (2.0 * eye - dense @ M)
+            if defect(M) < 1e-12:
+                break
+        if not bool(torch.isfinite(M).all()) or defect(M) >= tol:
+            raise ValueError("coarsest operator is numerically singular (cannot be inverted)")
+    return M.contiguous()
+
+
+class DenseInverse:
+    kind = "dense"
+
+    def __init__(self, A, ops_mod):
+        self.ops = ops_mod
+        n = A.shape[0]
+        if n > MAX_DENSE:
+            raise ValueError("coarsest level has %d unknowns (> %d): use more levels" % (n, MAX_DENSE))
+        self.inv = dense_inverse(csr_to_dense(A))
+        self.n = n
+
+    def apply(self, b, x):
+        self.ops.dense_gemv(self.inv, b, x)
+
+    def bytes_per_apply(self):
+        return 8 * self.n * self.n
+
+
+def half_bandwidth(A_host):
+    coo = A_host.tocoo()
+    return int(np.abs(coo.row - coo.col).max()) if coo.nnz else 0
+
+
+class BandedBlockSolver:
+    kind = "banded-block"
+
+    @staticmethod
+    def plan(n, w):
+        """(k strips, strip size s) minimising the dense bytes per application
+        2*k*s^2 + ((k-1)*w')^2 with equal even strip sizes, or None if banding does not pay."""
+        best = None
+        for k in range(2, 129):
+            s = (n - (k - 1) * w) // k
+            s -= s % 2
+            if s < 2 * w or s < 32:
+                break
+            ns = n - k * s
+            cost = 2 * k * s * s + ns * ns
+            if best is None or cost < best[0]:
+                best = (cost, k, s)
+        if best is None or best[0] > 0.5 * n * n:
+            return None
+        return best[1], best[2]
+
+    def __init__(self, A, ops_mod, k, s):
+        self.ops = ops_mod
+        dev = A.device
+        n = A.shape[0]
+        Ah = sp.csr_matrix((A.vals.cpu().numpy(), A.colidx.cpu().numpy(), A.rowptr.cpu().numpy()), shape=A.shape)
+        w = half_bandwidth(Ah)
+        ns = n - k * s                                # all separator unknowns
+        base, extra = divmod(ns, k - 1)               # separator sizes, each >= w
+        if base < w:
+            raise ValueError("separators thinner than the bandwidth")
+        strips, seps, pos = [], [], 0
+        for i in range(k):
+            strips.append(np.arange(pos, pos + s))
+            pos += s
+            if i < k - 1:
+                sz = base + (1 if i < extra else 0)
+                seps.append(np.arange(pos, pos + sz))
+                pos += sz
+        assert pos == n
+        I = np.concatenate(strips)
+        S = np.concatenate(seps)
+        self.n, self.nI, self.nS, self.k, self.s, self.w = n, I.size, S.size, k, s, w
+        perm = np.concatenate([I, S])
+        A_II = Ah[I][:, I].tocsr()
+        # strips must be mutually decoupled: A_II is block diagonal with s x s blocks
+        coo = A_II.tocoo()
+        if coo.nnz and np.any(coo.row // s != coo.col // s):
+            raise ValueError("strips are coupled: the operator is not banded in this ordering")
+        A_IS = Ah[I][:, S].tocsr()
+        A_SI = Ah[S][:, I].tocsr()
+        A_SS = Ah[S][:, S].toarray()
+        blocks = torch.empty((k, s, s), dtype=F64, device=dev)
+        for i in range(k):
+            blk = A_II[i * s:(i + 1) * s, i * s:(i + 1) * s].toarray()
+            blocks[i] = dense_inverse(torch.from_numpy(blk).to(dev))
+        self.blocks = blocks.contiguous()
+        # Schur complement S = A_SS - A_SI A_II^-1 A_IS, strip by strip (dense GEMMs, setup only)
+        Sc = torch.from_numpy(A_SS).to(dev)
+        for i in range(k):
+            rows = slice(i * s, (i + 1) * s)
+            Ais = torch.from_numpy(A_IS[rows].toarray()).to(dev)            # s x nS
+            Asi = torch.from_numpy(A_SI[:, rows].toarray()).to(dev)         # nS x s
+            Sc -= Asi @ (self.blocks[i] @ Ais)
+        self.Sinv = dense_inverse(Sc)
+        self.A_IS = DeviceCSR.from_scipy(A_IS, dev)
+        self.A_SI = DeviceCSR.from_scipy(A_SI, dev)
+        self.perm = torch.from_numpy(perm.astype(np.int32)).to(dev)
+        z = lambda m: torch.zeros(m, dtype=F64, device=dev)
+        self.bp, self.xp, self.y, self.t = z(n), z(n), z(self.nI), z(self.nI)
+
+    def apply(self, b, x):
+        o = self.ops
+        nI = self.nI
+        o.gather(self.perm, b, self.bp)                           # permuted rhs [b_I | b_S]
+        bI, bS = self.bp[:nI], self.bp[nI:]
+        xI, xS = self.xp[:nI], self.xp[nI:]
+        o.dense_gemv_blockdiag(self.blocks, bI, self.y)           # y_I = A_II^-1 b_I
+        o.csr_spmv(self.A_SI, self.y, bS, -1.0, 1.0)              # g_S = b_S - A_SI y_I   (in place)
+        o.dense_gemv(self.Sinv, bS, xS)                           # x_S = S^-1 g_S
+        o.copy(bI, self.t)
+        o.csr_spmv(self.A_IS, xS, self.t, -1.0, 1.0)              # t_I = b_I - A_IS x_S
+        o.dense_gemv_blockdiag(self.blocks, self.t, xI)           # x_I = A_II^-1 t_I
+        o.scatter(self.perm, self.xp, x)
+
+    def bytes_per_apply(self):
+        return 8 * (2 * self.k * self.s * self.s + self.nS * self.nS)
+
+
+def make_coarse_solver(A, ops_mod, strategy="auto"):
+    """strategy: "auto" | "dense" | "banded"."""
+    n = A.shape[0]
+    if strategy not in ("auto", "dense", "banded"):
+        raise ValueError("unknown coarse solver strategy %r" % (strategy,))
+    if strategy != "dense" and n >= 2048:
+        Ah = sp.csr_matrix((A.vals.cpu().numpy(), A.colidx.cpu().numpy(), A.rowptr.cpu().numpy()), shape=A.shape)
+        plan = BandedBlockSolver.plan(n, max(half_bandwidth(Ah), 1))
+        if plan is not None:
+            try:
+                return BandedBlockSolver(A, ops_mod, *plan)
+            except (ValueError, RuntimeError):
+                if strategy == "banded":
+                    raise
+        elif strategy == "banded":
+            raise ValueError("operator is not narrow-banded: cannot use the banded coarse solver")
+    return DenseInverse(A, ops_mod)

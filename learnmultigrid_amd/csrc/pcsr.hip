@@ -78,7 +78,9 @@ __device__ __forceinline__ void stage_bytes(const unsigned char *g, long lo16, l
         *reinterpret_cast<v4u *>(s + (off - lo16)) = *reinterpret_cast<const v4u *>(g + off);
 }
 
-template <int MODE, int COLMODE, int VALMODE>
+// JU = entries of each row handled per step (JU x 4 independent gathers in flight per thread)
+// EXP (timing experiments only, wrong results): 1 = no x gathers, 2 = no gathers and no staging
+template <int MODE, int COLMODE, int VALMODE, int JU, int EXP = 0>
 __global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
 {
     typedef typename ColT<COLMODE>::type col_t;
@@ -131,10 +133,12 @@ __global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
         // ---- stage the packed streams (still packed) ---------------------------------------
         const int ac = base & ~(CPER - 1);          // first staged entry of each stream
         const int av = base & ~(VPER - 1);
-        stage_bytes(reinterpret_cast<const unsigned char *>(a.col), (long)ac * sizeof(col_t),
-                    (long)end * sizeof(col_t), s_colb, t);
-        stage_bytes(reinterpret_cast<const unsigned char *>(a.val), (long)av * sizeof(val_t),
-                    (long)end * sizeof(val_t), s_valb, t);
+        if (EXP != 2) {
+            stage_bytes(reinterpret_cast<const unsigned char *>(a.col), (long)ac * sizeof(col_t),
+                        (long)end * sizeof(col_t), s_colb, t);
+            stage_bytes(reinterpret_cast<const unsigned char *>(a.val), (long)av * sizeof(val_t),
+                        (long)end * sizeof(val_t), s_valb, t);
+        }
         __syncthreads();
 
         // entry offset of each of this thread's 4 rows (k-major row order inside the tile)
@@ -161,28 +165,37 @@ __global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
             xi[k] = 0.0;
             maxlen = max(maxlen, len[k]);
         }
-        for (int j = 0; j < maxlen; ++j) {
-            int c[kRpt];
-            double v[kRpt], xv[kRpt];
+        for (int j0 = 0; j0 < maxlen; j0 += JU) {
+            int c[JU][kRpt];
+            double v[JU][kRpt], xv[JU][kRpt];
 #pragma unroll
-            for (int k = 0; k < kRpt; ++k) {
-                const int p = (j < len[k]) ? rs[k] + j : base;
-                c[k] = cb0 + (int)s_col[p - ac];
-                if constexpr (VALMODE == VAL8) v[k] = s_dict[s_val[p - av]];
-                else if constexpr (VALMODE == VAL16) v[k] = a.dict[s_val[p - av]];
-                else v[k] = s_val[p - av];
+            for (int jj = 0; jj < JU; ++jj) {
+#pragma unroll
+                for (int k = 0; k < kRpt; ++k) {
+                    const int p = (j0 + jj < len[k]) ? rs[k] + j0 + jj : base;
+                    c[jj][k] = cb0 + (int)s_col[p - ac];
+                    if constexpr (VALMODE == VAL8) v[jj][k] = s_dict[s_val[p - av]];
+                    else if constexpr (VALMODE == VAL16) v[jj][k] = a.dict[s_val[p - av]];
+                    else v[jj][k] = s_val[p - av];
+                }
             }
 #pragma unroll
-            for (int k = 0; k < kRpt; ++k) xv[k] = a.x[c[k]];
+            for (int jj = 0; jj < JU; ++jj) {
 #pragma unroll
-            for (int k = 0; k < kRpt; ++k) {
-                const bool act = j < len[k];
-                const double s2 = acc[k] + v[k] * xv[k];
-                acc[k] = act ? s2 : acc[k];
-                if (MODE == MODE_JACOBI) {
-                    const bool dg = act && (c[k] == r0 + k * kBlock + t);
-                    diag[k] = dg ? diag[k] + v[k] : diag[k];
-                    xi[k] = dg ? xv[k] : xi[k];
+                for (int k = 0; k < kRpt; ++k) xv[jj][k] = EXP ? (double)c[jj][k] : a.x[c[jj][k]];
+            }
+#pragma unroll
+            for (int jj = 0; jj < JU; ++jj) {
+#pragma unroll
+                for (int k = 0; k < kRpt; ++k) {
+                    const bool act = j0 + jj < len[k];
+                    const double s2 = acc[k] + v[jj][k] * xv[jj][k];
+                    acc[k] = act ? s2 : acc[k];
+                    if (MODE == MODE_JACOBI) {
+                        const bool dg = act && (c[jj][k] == r0 + k * kBlock + t);
+                        diag[k] = dg ? diag[k] + v[jj][k] : diag[k];
+                        xi[k] = dg ? xv[jj][k] : xi[k];
+                    }
                 }
             }
         }
@@ -242,20 +255,56 @@ int lds_bytes(int cap, int colmode, int valmode)
     return (valmode == VAL8 ? 2048 : 0) + ((cap * cs + 15) & ~15) + 16 + ((cap * vs + 15) & ~15) + 16 + 32 + 16;
 }
 
+int g_pcsr_ju = 0;      // 0 = pick from the average row length; 1, 2, 3, 5 = forced (tuning)
+
+template <int MODE, int COLMODE, int VALMODE, int JU>
+int launch_ju(PArgs a, hipStream_t st);
+
 template <int MODE, int COLMODE, int VALMODE>
 int launch(PArgs a, hipStream_t st)
+{
+    int ju = g_pcsr_ju;
+    if (ju == 0) {
+        // measured on MI355X (tools/tune_sweep.py): short rows want the smallest register
+        // footprint (JU 1); ~9-entry rows want 3 steps of 3, or 2 steps of 5 when the gathers
+        // go to a much longer vector (restriction: SpMV mode)
+        const double avg = (double)a.nnz / (double)a.n;
+        ju = avg <= 6.0 ? 1 : (MODE == MODE_SPMV ? 5 : 3);
+    }
+    if (ju == 101 || ju == 102) {
+        if (COLMODE != COL16 || VALMODE != VAL8) return LMG_ERR_ARG;
+        const int lds = lds_bytes(a.cap, COLMODE, VALMODE);
+        int64_t grid = 256 * 10;
+        if (grid > (int64_t)a.tiles_per_xcd * 8) grid = (int64_t)a.tiles_per_xcd * 8;
+        if (ju == 101)
+            hipLaunchKernelGGL((pcsr_sweep_kernel<MODE, COL16, VAL8, 1, 1>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+        else
+            hipLaunchKernelGGL((pcsr_sweep_kernel<MODE, COL16, VAL8, 1, 2>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+        LMG_CHECK_LAUNCH();
+        return LMG_OK;
+    }
+    switch (ju) {
+    case 1: return launch_ju<MODE, COLMODE, VALMODE, 1>(a, st);
+    case 2: return launch_ju<MODE, COLMODE, VALMODE, 2>(a, st);
+    case 5: return launch_ju<MODE, COLMODE, VALMODE, 5>(a, st);
+    default: return launch_ju<MODE, COLMODE, VALMODE, 3>(a, st);
+    }
+}
+
+template <int MODE, int COLMODE, int VALMODE, int JU>
+int launch_ju(PArgs a, hipStream_t st)
 {
     const int lds = lds_bytes(a.cap, COLMODE, VALMODE);
     if (lds > kMaxLds) return LMG_ERR_CAPACITY;
     // persistent grid: exactly as many workgroups per CU as registers + LDS admit
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcsr_sweep_kernel<MODE, COLMODE, VALMODE>,
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcsr_sweep_kernel<MODE, COLMODE, VALMODE, JU>,
                                                      kBlock, (size_t)lds) != hipSuccess || per_cu < 1)
         per_cu = 4;
     if (per_cu > 16) per_cu = 16;
     int64_t grid = 256 * (int64_t)per_cu;
     if (grid > (int64_t)a.tiles_per_xcd * 8) grid = (int64_t)a.tiles_per_xcd * 8;
-    hipLaunchKernelGGL((pcsr_sweep_kernel<MODE, COLMODE, VALMODE>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    hipLaunchKernelGGL((pcsr_sweep_kernel<MODE, COLMODE, VALMODE, JU>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }
@@ -276,6 +325,14 @@ int dispatch(PArgs a, int colmode, int valmode, hipStream_t st)
 }
 
 }  // namespace
+
+int lmg_pcsr_tune_set(int ju)
+{
+    if (ju != 0 && ju != 1 && ju != 2 && ju != 3 && ju != 5 && ju != 101 && ju != 102) return LMG_ERR_ARG;
+    g_pcsr_ju = ju;
+    return LMG_OK;
+}
+int lmg_pcsr_tune_get(void) { return g_pcsr_ju; }
 
 extern "C" {
 

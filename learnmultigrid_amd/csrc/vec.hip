@@ -5,6 +5,8 @@
 
 int lmg_sweep_tune_set(int rpt);
 int lmg_sweep_tune_get(void);
+int lmg_pcsr_tune_set(int ju);
+int lmg_pcsr_tune_get(void);
 
 namespace {
 
@@ -82,8 +84,10 @@ __global__ void __launch_bounds__(kBlock) scatter_kernel(int64_t n, const int *i
 
 // Dense y = M x, one wave per row, 16 bytes per lane per step, fixed summation order.
 // HBM-bound: 8*n*m bytes of M per call.
+// With bs > 0 the matrix is block diagonal, stored as n/bs dense bs x m blocks one after the
+// other: row r multiplies the x segment of its block, x[(r/bs)*m .. +m).
 __global__ void __launch_bounds__(kBlock) dense_gemv_kernel(int64_t n, int64_t m, const double *M,
-                                                            const double *x, double *y)
+                                                            const double *x0, double *y, int64_t bs)
 {
     const int lane = threadIdx.x & (LMG_WAVE - 1);
     const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LMG_WAVE;
@@ -91,6 +95,7 @@ __global__ void __launch_bounds__(kBlock) dense_gemv_kernel(int64_t n, int64_t m
     const bool vec_ok = (m % 2 == 0);
     for (int64_t row = wave; row < n; row += nwaves) {
         const double *Mr = M + row * m;
+        const double *x = bs > 0 ? x0 + (row / bs) * m : x0;
         double s = 0.0;
         if (vec_ok) {
             const double2 *M2 = reinterpret_cast<const double2 *>(Mr);
@@ -215,6 +220,7 @@ int lmg_tune_set(const char *key, int value)
 {
     if (!key) return LMG_ERR_ARG;
     if (strcmp(key, "sweep_variant") == 0) return lmg_sweep_tune_set(value);
+    if (strcmp(key, "pcsr_ju") == 0) return lmg_pcsr_tune_set(value);
     return LMG_ERR_ARG;
 }
 
@@ -222,6 +228,7 @@ int lmg_tune_get(const char *key)
 {
     if (!key) return LMG_ERR_ARG;
     if (strcmp(key, "sweep_variant") == 0) return lmg_sweep_tune_get();
+    if (strcmp(key, "pcsr_ju") == 0) return lmg_pcsr_tune_get();
     return LMG_ERR_ARG;
 }
 
@@ -290,7 +297,19 @@ int lmg_dense_gemv(int64_t n, int64_t m, const double *M, const double *x, doubl
     if (n == 0) return LMG_OK;
     if (!lmg_aligned16(M) || !lmg_aligned16(x)) return LMG_ERR_ALIGN;
     hipLaunchKernelGGL(dense_gemv_kernel, dim3(grid_for(n, kBlock / LMG_WAVE)), dim3(kBlock), 0,
-                       lmg_stream(stream), n, m, M, x, y);
+                       lmg_stream(stream), n, m, M, x, y, (int64_t)0);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_dense_gemv_blockdiag(int64_t nblocks, int64_t bs, const double *M, const double *x, double *y,
+                             void *stream)
+{
+    if (nblocks < 0 || bs < 0 || (nblocks * bs > 0 && (!M || !x || !y)) || x == y) return LMG_ERR_ARG;
+    if (nblocks * bs == 0) return LMG_OK;
+    if (!lmg_aligned16(M) || !lmg_aligned16(x) || (bs % 2)) return LMG_ERR_ALIGN;
+    hipLaunchKernelGGL(dense_gemv_kernel, dim3(grid_for(nblocks * bs, kBlock / LMG_WAVE)), dim3(kBlock), 0,
+                       lmg_stream(stream), nblocks * bs, bs, M, x, y, bs);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }

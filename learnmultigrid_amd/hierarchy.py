@@ -21,9 +21,8 @@ import scipy.sparse as sp
 import torch
 
 from . import ops
+from .coarse import MAX_DENSE as MAX_DENSE_COARSE, csr_to_dense, dense_inverse, make_coarse_solver  # noqa: F401
 from .ops import DeviceCSR, F64
-
-MAX_DENSE_COARSE = 46000      # 46000^2 * 8 B = 17 GB of the 288 GB HBM
 
 
 def _to_csr_host(M):
@@ -34,76 +33,6 @@ def _to_csr_host(M):
         M = M.copy()
         M.sum_duplicates()
     return M
-
-
-def csr_to_dense(A):
-    n, m = A.shape
-    dense = torch.zeros((n, m), dtype=F64, device=A.device)
-    rows = torch.repeat_interleave(torch.arange(n, device=A.device),
-                                   (A.rowptr[1:] - A.rowptr[:-1]).long())
-    dense.index_put_((rows, A.colidx.long()), A.vals, accumulate=True)
-    return dense
-
-
-_INV_LEAF = 512
-
-
-def _inv_schur(A):
-    """Recursive 2x2 Schur-complement inversion: only small leaf inversions and plain
-    rocBLAS GEMMs (torch.matmul).  No pivoting across blocks -- fine for the M-matrix-like
-    Galerkin operators this is used on; dense_inverse() verifies and repairs the result."""
-    n = A.shape[0]
-    if n <= _INV_LEAF:
-        return torch.linalg.inv(A)
-    k = n // 2
-    A11, A12, A21, A22 = A[:k, :k], A[:k, k:], A[k:, :k], A[k:, k:]
-    I11 = _inv_schur(A11.contiguous())
-    T = I11 @ A12
-    IS = _inv_schur((A22 - A21 @ T).contiguous())
-    W = IS @ (A21 @ I11)
-    out = torch.empty_like(A)
-    out[k:, k:] = IS
-    out[k:, :k] = -W
-    out[:k, k:] = -(T @ IS)
-    out[:k, :k] = I11 + T @ W
-    return out
-
-
-def dense_inverse(dense, polish=2, tol=1e-9):
-    """A^-1 on the device (SETUP phase of the coarsest level / DirectSolver).
-
-    rocSOLVER's getri/getrs path (torch.linalg.inv / lu_solve) is used while it works, but
-    it cannot get its trsm workspace for n ~ 16 000 on this stack (HIPBLAS_STATUS_ALLOC_FAILED),
-    so large operators are inverted by block Schur recursion on GEMMs, polished by `polish` Newton-Schulz steps
-    M <- M (2I - A M), and verified: max|I - A M| must drop below `tol`, otherwise a pure
-    Newton-Schulz iteration from A^T/(|A|_1 |A|_inf) (convergent for every nonsingular A)
-    takes over; if that fails too the operator is reported singular."""
-    n = dense.shape[0]
-    eye = torch.eye(n, dtype=F64, device=dense.device)
-
-    def defect(M):
-        return float((eye - dense @ M).abs().max())
-
-    try:                                   # pivoted LU (rocSOLVER) while it can get workspace
-        M = torch.linalg.inv(dense)
-        steps = 0
-    except RuntimeError:
-        M = _inv_schur(dense)
-        steps = polish
-    ok = bool(torch.isfinite(M).all())
-    if ok:
-        for _ in range(steps):
-            M = M @ (2.0 * eye - dense @ M)
-        ok = bool(torch.isfinite(M).all()) and defect(M) < tol
-    if not ok:
-        M = dense.t().contiguous() / (dense.abs().sum(0).max() * dense.abs().sum(1).max())
-        for _ in range(200):
-            M = M @ (2.0 * eye - dense @ M)
-            if defect(M) < 1e-12:
-                break
-        if not bool(torch.isfinite(M).all()) or defect(M) >= tol:
-            raise ValueError("coarsest operator is numerically singular (cannot be inverted)")
-    return M.contiguous()
 
 
 class Level:
@@ -128,13 +57,14 @@ class Hierarchy:
     """levels[0] is the fine grid; transfers[l] (n_l x n_{l+1}) prolongates level l+1 -> l."""
 
     def __init__(self, A, transfers, device, coarse_refine=1, verbose=False, ops_mod=None,
-                 use_packed=True):
+                 use_packed=True, coarse_solver="auto"):
         # `ops_mod` exists for the CPU-only host-logic tests (a test shim stands in for the
         # HIP kernels); the product always runs with learnmultigrid_amd.ops.
         self.ops = ops if ops_mod is None else ops_mod
         ops_ = self.ops
         self.device = torch.device(device)
         self.coarse_refine = int(coarse_refine)
+        self.coarse_strategy = coarse_solver
         self.verbose = verbose
         # every launch of this hierarchy goes to one explicit HIP stream (the legacy default
         # stream cannot be captured into a hipGraph)
@@ -184,11 +114,9 @@ class Hierarchy:
                     M.pack()
 
     def _factor_coarsest(self):
-        Ac = self.levels[-1].A
-        n = Ac.shape[0]
-        if n > MAX_DENSE_COARSE:
-            raise ValueError("coarsest level has %d unknowns (> %d): use more levels" % (n, MAX_DENSE_COARSE))
-        self.coarse_inv = dense_inverse(csr_to_dense(Ac))
+        """Direct solver of the coarsest operator (setup): dense inverse, or the banded block
+        elimination of coarse.py when the operator is narrow-banded (grid problems)."""
+        self.coarse = make_coarse_solver(self.levels[-1].A, self.ops, self.coarse_strategy)
 
     def rebuild_numeric(self, new_vals):
         """Galerkin rebuild after the VALUES of the fine matrix changed (same pattern):
@@ -233,10 +161,10 @@ class Hierarchy:
 
     def coarse_solve(self):
         lev = self.levels[-1]
-        self.ops.dense_gemv(self.coarse_inv, lev.b, lev.x)
+        self.coarse.apply(lev.b, lev.x)
         for _ in range(self.coarse_refine):
             self.ops.csr_residual_norm2(lev.A, lev.x, lev.b, lev.r, None, None)
-            self.ops.dense_gemv(self.coarse_inv, lev.r, lev.tmp)
+            self.coarse.apply(lev.r, lev.tmp)
             self.ops.axpby(1.0, lev.tmp, 1.0, lev.x)
 
     def cycle(self, smoother, steps, omega=1.0, gs_mode="lexicographic", l=0, depth=None,
@@ -290,7 +218,7 @@ class Hierarchy:
             for M in (lev.P, lev.R, lev.RA):
                 if M is not None:
                     tot += M.bytes()
-        return tot + self.coarse_inv.numel() * 8
+        return tot + self.coarse.bytes_per_apply()
 
     def cycle_bytes(self, steps):
         """Algorithmic HBM bytes of one V(steps,steps) cycle: per level
@@ -302,6 +230,5 @@ class Hierarchy:
             tot += (2 * steps + 1) * (12 * nnz + 4 * (n + 1) + 24 * n)
             tot += 12 * lev.R.nnz + 4 * (nc + 1) + 8 * n + 8 * nc
             tot += 12 * lev.P.nnz + 4 * (n + 1) + 8 * nc + 16 * n
-        nL = self.levels[-1].n
-        coarse = (1 + self.coarse_refine) * 8 * nL * nL
+        coarse = (1 + self.coarse_refine) * self.coarse.bytes_per_apply()
         return tot, coarse

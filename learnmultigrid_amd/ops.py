@@ -316,6 +316,13 @@ def dense_gemv(M, x, y):
     check(_lib.lib().lmg_dense_gemv(M.shape[0], M.shape[1], _p(M), _p(x), _p(y), _s()), "lmg_dense_gemv")
 
 
+def dense_gemv_blockdiag(M, x, y):
+    """M: (nblocks, bs, bs) contiguous; x, y: nblocks*bs."""
+    _vec_ok(M, x, y)
+    check(_lib.lib().lmg_dense_gemv_blockdiag(M.shape[0], M.shape[1], _p(M), _p(x), _p(y), _s()),
+          "lmg_dense_gemv_blockdiag")
+
+
 # ---- SpGEMM ---------------------------------------------------------------------------------
 def exclusive_scan_i32(inp, out):
     n = inp.numel()

@@ -83,6 +83,12 @@ def dense_gemv(M, x, y):
     _np(y)[:] = K.dense_gemv(_np(M), _np(x))
 
 
+def dense_gemv_blockdiag(M, x, y):
+    k, s, _ = M.shape
+    for i in range(k):
+        _np(y)[i * s:(i + 1) * s] = K.dense_gemv(_np(M[i]), _np(x)[i * s:(i + 1) * s])
+
+
 class SpGEMMPlan:
     def __init__(self, A, B):
         self.shape = (A.shape[0], B.shape[1])

@@ -1,0 +1,65 @@
+"""Host logic of the coarsest-level solvers (coarse.py) on CPU tensors with the test-only
+ops shim: the banded block elimination must reproduce SuperLU (`spsolve`, the reference's
+Multigrid.py:106) to rounding, and the planner must only pick it for narrow-banded operators."""
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+import torch
+
+import cpu_ops_shim as shim
+from learnmultigrid_amd import coarse, problems as P
+from learnmultigrid_amd.ops import DeviceCSR
+
+
+def galerkin_operator(m):
+    A, _ = P.poisson_2d_structured(2 * m)
+    Pm = P.tensor_interpolator_2d(2 * m + 1)
+    Ac = sp.csr_matrix(Pm.T @ A @ Pm)
+    Ac.sort_indices()
+    return Ac
+
+
+def test_plan_prefers_banding_only_when_it_pays():
+    assert coarse.BandedBlockSolver.plan(129 * 129, 130) is not None
+    k, s = coarse.BandedBlockSolver.plan(129 * 129, 130)
+    assert s % 2 == 0 and k * s + (k - 1) * 130 <= 129 * 129
+    assert 2 * k * s * s + (129 * 129 - k * s) ** 2 < 0.15 * (129 * 129) ** 2      # > 6x fewer bytes
+    assert coarse.BandedBlockSolver.plan(1000, 400) is None                          # wide band: dense
+
+
+def test_banded_block_solver_matches_superlu():
+    Ac = galerkin_operator(64)                      # 65^2 = 4225 unknowns, 9-point, w = 66
+    n = Ac.shape[0]
+    assert coarse.half_bandwidth(Ac) == 66
+    dA = DeviceCSR.from_scipy(Ac, "cpu")
+    solver = coarse.make_coarse_solver(dA, shim, "auto")
+    assert solver.kind == "banded-block" and solver.k >= 4
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(n)
+    x = torch.zeros(n, dtype=torch.float64)
+    solver.apply(torch.from_numpy(b.copy()), x)
+    want = spla.spsolve(sp.csc_matrix(Ac), b)
+    err = np.linalg.norm(x.numpy() - want) / np.linalg.norm(want)
+    assert err < 1e-11, err
+    # one step of refinement against the true operator brings it to rounding level
+    r = b - Ac @ x.numpy()
+    d = torch.zeros(n, dtype=torch.float64)
+    solver.apply(torch.from_numpy(r), d)
+    x2 = x.numpy() + d.numpy()
+    assert np.linalg.norm(x2 - want) / np.linalg.norm(want) < 1e-13
+    dense = coarse.make_coarse_solver(dA, shim, "dense")
+    assert dense.kind == "dense" and dense.bytes_per_apply() > 5 * solver.bytes_per_apply()
+    y = torch.zeros(n, dtype=torch.float64)
+    dense.apply(torch.from_numpy(b.copy()), y)
+    assert np.linalg.norm(y.numpy() - want) / np.linalg.norm(want) < 1e-11
+
+
+def test_unstructured_numbering_falls_back_to_dense():
+    Ac = galerkin_operator(24)                       # 25^2 = 625 < 2048 -> dense by size
+    assert coarse.make_coarse_solver(DeviceCSR.from_scipy(Ac, "cpu"), shim).kind == "dense"
+    A, _ = P.poisson_2d_structured(48)               # 2401 unknowns, scrambled numbering: wide band
+    rng = np.random.default_rng(1)
+    p = rng.permutation(A.shape[0])
+    Ap = sp.csr_matrix(A[p][:, p])
+    Ap.sort_indices()
+    assert coarse.make_coarse_solver(DeviceCSR.from_scipy(Ap, "cpu"), shim).kind == "dense"

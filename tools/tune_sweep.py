@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--inner", type=int, default=10)
     ap.add_argument("--matrix", default="A0")
     ap.add_argument("--mode", default="jacobi", choices=["jacobi", "residual", "spmv"])
+    ap.add_argument("--ju", default="", help="packed kernel unroll factors to compare, e.g. 1,2,3,5 (variant = -ju)")
     ap.add_argument("--packed", type=int, default=0, help="1: also time the packed twin (reported as variant -1)")
     args = ap.parse_args()
     import torch
@@ -53,18 +54,21 @@ def main():
             ops.csr_spmv(dM, x, y, 1.0, 0.0)
 
     variants = [int(v) for v in args.variants.split(",")]
+    jus = [int(v) for v in args.ju.split(",")] if args.ju else []
     if args.packed:
         pk = dM.pack()
         print("packed: colmode %d valmode %d ndict %d bytes %d (csr %d)" % (pk.colmode, pk.valmode, pk.ndict, pk.bytes(), dM.bytes()))
-        variants = [-1] + variants
+        variants = ([-j for j in jus] if jus else [-1]) + variants
     ops.set_packed_enabled(False)
     times = {v: [] for v in variants}
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for rep in range(args.reps + 1):
         for v in variants:
-            ops.set_packed_enabled(v == -1)
+            ops.set_packed_enabled(v < 0)
             if v >= 0:
                 ops.tune_set("sweep_variant", v)
+            elif jus:
+                ops.tune_set("pcsr_ju", -v)
             launch()
             torch.cuda.synchronize()
             ev0.record()

@@ -128,6 +128,9 @@ int64_t lmg_host_greedy_colors(int64_t n, const int32_t *h_rowptr, const int32_t
 
 /* ---- vectors --------------------------------------------------------------------*/
 int lmg_axpby(int64_t n, double alpha, const double *d_x, double beta, double *d_y, void *stream);
+/* out = alpha * (x * y) elementwise.  With x = 1/diag(A), y = b, alpha = omega this is the
+ * Jacobi sweep from a zero initial guess (coarse levels start from zeros, Multigrid.py:103). */
+int lmg_vmul(int64_t n, double alpha, const double *d_x, const double *d_y, double *d_out, void *stream);
 int lmg_copy(int64_t n, const double *d_src, double *d_dst, void *stream);
 int lmg_zero(int64_t n, double *d_x, void *stream);
 int lmg_dot(int64_t n, const double *d_x, const double *d_y, double *d_partials, double *d_out,

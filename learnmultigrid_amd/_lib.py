@@ -35,6 +35,7 @@ SIGNATURES = {
     "lmg_host_gs_levels": (_i64, [_i64, _p, _p, _p]),
     "lmg_host_greedy_colors": (_i64, [_i64, _p, _p, _p]),
     "lmg_axpby": (_c.c_int, [_i64, _f64, _p, _f64, _p, _p]),
+    "lmg_vmul": (_c.c_int, [_i64, _f64, _p, _p, _p, _p]),
     "lmg_copy": (_c.c_int, [_i64, _p, _p, _p]),
     "lmg_zero": (_c.c_int, [_i64, _p, _p]),
     "lmg_dot": (_c.c_int, [_i64, _p, _p, _p, _p, _p]),

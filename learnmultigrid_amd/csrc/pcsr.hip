@@ -90,7 +90,8 @@ __global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // layout: [dict (VAL8: 2048 B)] [col bytes] [val bytes] [scan: 8 ints] [red: 2 doubles]
     double *s_dict = reinterpret_cast<double *>(smem);
-    const int dict_bytes = (VALMODE == VAL8) ? 2048 : 0;
+    const int dict_bytes = (VALMODE == VAL8) ? 4096 : 0;     // dictionary + its reciprocals
+    double *s_rdict = s_dict + 256;
     const int col_bytes = ((a.cap * (int)sizeof(col_t) + 15) & ~15) + 16;
     const int val_bytes = ((a.cap * (int)sizeof(val_t) + 15) & ~15) + 16;
     unsigned char *s_colb = smem + dict_bytes;
@@ -107,7 +108,13 @@ __global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
     if (t_begin + slot >= t_end) return;
 
     if (VALMODE == VAL8) {
-        for (int i = t; i < 256; i += kBlock) s_dict[i] = i < a.ndict ? a.dict[i] : 0.0;
+        for (int i = t; i < 256; i += kBlock) {
+            const double d = i < a.ndict ? a.dict[i] : 0.0;
+            s_dict[i] = d;
+            // Jacobi divides by the diagonal, which is a dictionary entry: one division per
+            // dictionary entry and workgroup instead of one per row (same IEEE division)
+            s_rdict[i] = (MODE == MODE_JACOBI && d != 0.0) ? 1.0 / d : 0.0;
+        }
     }
 
     for (int tile = t_begin + slot; tile < t_end; tile += nslots) {
@@ -157,16 +164,18 @@ __global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
         // independent, so one L2 round trip serves 4 rows (each row still accumulates its own
         // entries in storage order).  Inactive slots read the tile's first entry (valid).
         double acc[kRpt], diag[kRpt], xi[kRpt];
+        int didx[kRpt];                    // VAL8: dictionary index of the (single) diagonal entry
         int maxlen = 0;
 #pragma unroll
         for (int k = 0; k < kRpt; ++k) {
             acc[k] = 0.0;
             diag[k] = 0.0;
             xi[k] = 0.0;
+            didx[k] = -1;
             maxlen = max(maxlen, len[k]);
         }
         for (int j0 = 0; j0 < maxlen; j0 += JU) {
-            int c[JU][kRpt];
+            int c[JU][kRpt], vi[JU][kRpt];
             double v[JU][kRpt], xv[JU][kRpt];
 #pragma unroll
             for (int jj = 0; jj < JU; ++jj) {
@@ -174,8 +183,11 @@ __global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
                 for (int k = 0; k < kRpt; ++k) {
                     const int p = (j0 + jj < len[k]) ? rs[k] + j0 + jj : base;
                     c[jj][k] = cb0 + (int)s_col[p - ac];
-                    if constexpr (VALMODE == VAL8) v[jj][k] = s_dict[s_val[p - av]];
-                    else if constexpr (VALMODE == VAL16) v[jj][k] = a.dict[s_val[p - av]];
+                    vi[jj][k] = 0;
+                    if constexpr (VALMODE == VAL8) {
+                        vi[jj][k] = s_val[p - av];
+                        v[jj][k] = s_dict[vi[jj][k]];
+                    } else if constexpr (VALMODE == VAL16) v[jj][k] = a.dict[s_val[p - av]];
                     else v[jj][k] = s_val[p - av];
                 }
             }
@@ -195,6 +207,7 @@ __global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
                         const bool dg = act && (c[jj][k] == r0 + k * kBlock + t);
                         diag[k] = dg ? diag[k] + v[jj][k] : diag[k];
                         xi[k] = dg ? xv[jj][k] : xi[k];
+                        if (VALMODE == VAL8) didx[k] = dg ? (didx[k] == -1 ? vi[jj][k] : -2) : didx[k];
                     }
                 }
             }
@@ -210,8 +223,14 @@ __global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
                     local += r * r;
                 } else if (MODE == MODE_JACOBI) {
                     const double r = bv[k] - acc[k];
-                    if (diag[k] != 0.0) a.out[row] = xi[k] + a.alpha * ((1.0 / diag[k]) * r);
-                    else a.out[row] = a.x[row];
+                    if (diag[k] != 0.0) {
+                        double inv;
+                        if (VALMODE == VAL8 && didx[k] >= 0) inv = s_rdict[didx[k]];
+                        else inv = 1.0 / diag[k];
+                        a.out[row] = xi[k] + a.alpha * (inv * r);
+                    } else {
+                        a.out[row] = a.x[row];
+                    }
                 } else {
                     double s = acc[k];
                     if (a.alpha != 1.0) s = a.alpha * s;
@@ -252,7 +271,7 @@ int lds_bytes(int cap, int colmode, int valmode)
 {
     const int cs = colmode == COL16 ? 2 : 4;
     const int vs = valmode == VAL8 ? 1 : (valmode == VAL16 ? 2 : 8);
-    return (valmode == VAL8 ? 2048 : 0) + ((cap * cs + 15) & ~15) + 16 + ((cap * vs + 15) & ~15) + 16 + 32 + 16;
+    return (valmode == VAL8 ? 4096 : 0) + ((cap * cs + 15) & ~15) + 16 + ((cap * vs + 15) & ~15) + 16 + 32 + 16;
 }
 
 int g_pcsr_ju = 0;      // 0 = pick from the average row length; 1, 2, 3, 5 = forced (tuning)

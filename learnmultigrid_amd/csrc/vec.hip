@@ -48,6 +48,16 @@ __global__ void __launch_bounds__(kBlock) axpby_kernel(int64_t n, double alpha, 
     }
 }
 
+// out = alpha * (x * y) elementwise: the first Jacobi sweep from a zero initial guess,
+// x_1 = omega * (D^-1 b), bit-identical to the general sweep with x_0 = 0.
+__global__ void __launch_bounds__(kBlock) vmul_kernel(int64_t n, double alpha, const double *x,
+                                                      const double *y, double *out)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        out[i] = alpha * (x[i] * y[i]);
+}
+
 // fixed geometry (1024 partials) so the result does not depend on tuning knobs
 __global__ void __launch_bounds__(kBlock) dot_kernel(int64_t n, const double *x, const double *y,
                                                      double *partial)
@@ -239,6 +249,15 @@ int lmg_axpby(int64_t n, double alpha, const double *x, double beta, double *y, 
     if (!lmg_aligned16(x) || !lmg_aligned16(y)) return LMG_ERR_ALIGN;
     hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n, kBlock * 2)), dim3(kBlock), 0, lmg_stream(stream),
                        n, alpha, x, beta, y);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_vmul(int64_t n, double alpha, const double *x, const double *y, double *out, void *stream)
+{
+    if (n < 0 || (n > 0 && (!x || !y || !out))) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    hipLaunchKernelGGL(vmul_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, lmg_stream(stream), n, alpha, x, y, out);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }

@@ -153,6 +153,7 @@ class DistributedVCycle:
                                    torch.empty(mine.size, dtype=F64, device=self.device)))
             for name in ("x", "b", "r", "tmp"):
                 setattr(d, name, torch.zeros(d.n_tot, dtype=F64, device=self.device))
+            d.dinv = self.ops.csr_inverse_diagonal(d.A)
             self.dl.append(d)
         # P of level l acts on level l+1 vectors: distributed layout or the full replicated vector
         for l in range(self.n_dist):
@@ -245,28 +246,34 @@ class DistributedVCycle:
         return np.concatenate(parts)
 
     # ---- the cycle ---------------------------------------------------------------------------------------
-    def _smooth(self, d, steps, omega):
+    def _smooth(self, d, steps, omega, x_is_zero=False):
         o = self.ops
+        if x_is_zero and steps > 0:
+            # first sweep from zeros: x = omega * (D^-1 b), no halo needed
+            o.vmul(omega, d.dinv, d.b[:d.n_own], d.tmp[:d.n_own])
+            d.x, d.tmp = d.tmp, d.x
+            steps -= 1
+        elif x_is_zero:
+            o.zero(d.x)
         for _ in range(steps):
             self.exchange(d, d.x)
             o.csr_jacobi(d.A, d.x, d.b, omega, d.tmp)
             d.x, d.tmp = d.tmp, d.x
 
-    def cycle(self, smoother, steps, omega=1.0, l=0):
+    def cycle(self, smoother, steps, omega=1.0, l=0, x_is_zero=False):
         if smoother != "Jacobi":
             raise ValueError("the distributed V-cycle supports the Jacobi smoother only "
                              "(lexicographic Gauss-Seidel is sequential across ranks)")
         o = self.ops
         d = self.dl[l]
-        self._smooth(d, steps, omega)
+        self._smooth(d, steps, omega, x_is_zero)
         self.exchange(d, d.x)
         o.csr_residual_norm2(d.A, d.x, d.b, d.r, None, None)
         self.exchange(d, d.r)
         if l + 1 < self.n_dist:
             nxt = self.dl[l + 1]
             o.csr_spmv(d.R, d.r, nxt.b[:nxt.n_own], 1.0, 0.0)
-            o.zero(nxt.x)
-            self.cycle(smoother, steps, omega, l + 1)
+            self.cycle(smoother, steps, omega, l + 1, x_is_zero=True)
             self.exchange(nxt, nxt.x)
             o.csr_spmv(d.P, nxt.x, d.x[:d.n_own], 1.0, 1.0)
         else:
@@ -277,8 +284,7 @@ class DistributedVCycle:
             if l + 2 == len(self.full.levels):
                 self.full.coarse_solve()
             else:
-                o.zero(fl.x)
-                self.full.cycle(smoother, steps, omega, l=l + 1)
+                self.full.cycle(smoother, steps, omega, l=l + 1, x_is_zero=True)
             o.csr_spmv(d.P, fl.x, d.x[:d.n_own], 1.0, 1.0)
         self._smooth(d, steps, omega)
 

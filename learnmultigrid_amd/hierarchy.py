@@ -37,7 +37,7 @@ def _to_csr_host(M):
 
 class Level:
     __slots__ = ("n", "A", "P", "R", "x", "b", "r", "tmp", "plan_RA", "plan_RAP", "RA",
-                 "gs_sched", "host_pattern")
+                 "gs_sched", "host_pattern", "dinv")
 
     def __init__(self, A):
         self.n = A.shape[0]
@@ -51,6 +51,7 @@ class Level:
         self.tmp = torch.zeros(self.n, dtype=F64, device=dev)
         self.gs_sched = {}
         self.host_pattern = None
+        self.dinv = None
 
 
 class Hierarchy:
@@ -93,6 +94,7 @@ class Hierarchy:
             self.levels.append(Level(Ac))
         self.use_packed = bool(use_packed)
         self._pack_all()
+        self._inverse_diagonals()
         self.partials = torch.empty(ops_.partials_count(self.levels[0].n), dtype=F64, device=self.device)
         self.outer_r = torch.zeros(self.levels[0].n, dtype=F64, device=self.device)
         self.norm2 = torch.zeros(1, dtype=F64, device=self.device)
@@ -113,6 +115,12 @@ class Hierarchy:
                 if M is not None and hasattr(M, "pack"):
                     M.pack()
 
+    def _inverse_diagonals(self):
+        # for the zero-initial-guess first sweep on coarse levels (allocated at setup so that
+        # nothing has to be allocated while a hipGraph is being captured)
+        for lev in self.levels[1:-1]:
+            lev.dinv = self.ops.csr_inverse_diagonal(lev.A)
+
     def _factor_coarsest(self):
         """Direct solver of the coarsest operator (setup): dense inverse, or the banded block
         elimination of coarse.py when the operator is narrow-banded (grid problems)."""
@@ -132,6 +140,7 @@ class Hierarchy:
         for lev in self.levels:
             lev.A.invalidate_packed()
         self._pack_all()
+        self._inverse_diagonals()
         self._factor_coarsest()
         self._graphs = {}
 
@@ -146,13 +155,26 @@ class Hierarchy:
         return lev.gs_sched[kind]
 
     # ------------------------------------------------------------------ solve ----------
-    def smooth(self, l, smoother, steps, omega, gs_mode):
+    def smooth(self, l, smoother, steps, omega, gs_mode, x_is_zero=False):
+        """`steps` smoothing sweeps on level l.  x_is_zero: the iterate is known to be zero
+        (coarse levels start from zeros, Multigrid.py:103): the first Jacobi sweep then is
+        x = omega * (D^-1 b) -- same bits, a third of the bytes -- and nobody has to clear x."""
         lev = self.levels[l]
         if steps <= 0:
+            if x_is_zero:
+                self.ops.zero(lev.x)
             return
         if smoother == "GaussSeidel":
+            if x_is_zero:
+                self.ops.zero(lev.x)
             self.ops.csr_gs_schedule(lev.A, lev.x, lev.b, self.gs_schedule(l, gs_mode), steps)
         elif smoother == "Jacobi":
+            if x_is_zero:
+                if lev.dinv is None:
+                    lev.dinv = self.ops.csr_inverse_diagonal(lev.A)
+                self.ops.vmul(omega, lev.dinv, lev.b, lev.tmp)
+                lev.x, lev.tmp = lev.tmp, lev.x
+                steps -= 1
             for _ in range(steps):
                 self.ops.csr_jacobi(lev.A, lev.x, lev.b, omega, lev.tmp)
                 lev.x, lev.tmp = lev.tmp, lev.x
@@ -168,12 +190,12 @@ class Hierarchy:
             self.ops.axpby(1.0, lev.tmp, 1.0, lev.x)
 
     def cycle(self, smoother, steps, omega=1.0, gs_mode="lexicographic", l=0, depth=None,
-              after_presmooth=None):
+              after_presmooth=None, x_is_zero=False):
         """One V(steps, steps) cycle on level l: levels[l].x is the iterate, levels[l].b the
         right-hand side (Multigrid.py:77-124).  depth = number of grids used."""
         last = (len(self.levels) if depth is None else depth) - 1
         lev, nxt = self.levels[l], self.levels[l + 1]
-        self.smooth(l, smoother, steps, omega, gs_mode)                       # :88
+        self.smooth(l, smoother, steps, omega, gs_mode, x_is_zero)            # :88
         if after_presmooth is not None:
             after_presmooth(lev.x)
         self.ops.csr_residual_norm2(lev.A, lev.x, lev.b, lev.r, None, None)        # :90
@@ -181,8 +203,7 @@ class Hierarchy:
         if l + 1 == last:
             self.coarse_solve()                                               # :106
         else:
-            self.ops.zero(nxt.x)                                                   # :103
-            self.cycle(smoother, steps, omega, gs_mode, l + 1, depth)
+            self.cycle(smoother, steps, omega, gs_mode, l + 1, depth, x_is_zero=True)   # zeros, :103
         self.ops.csr_spmv(lev.P, nxt.x, lev.x, 1.0, 1.0)                           # :115
         self.smooth(l, smoother, steps, omega, gs_mode)                       # :121
 

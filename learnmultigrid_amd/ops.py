@@ -288,6 +288,23 @@ def axpby(alpha, x, beta, y):
     check(_lib.lib().lmg_axpby(y.numel(), float(alpha), _p(x), float(beta), _p(y), _s()), "lmg_axpby")
 
 
+def vmul(alpha, x, y, out):
+    _vec_ok(x, y, out)
+    check(_lib.lib().lmg_vmul(out.numel(), float(alpha), _p(x), _p(y), _p(out), _s()), "lmg_vmul")
+
+
+def csr_inverse_diagonal(A):
+    """1/a_ii per row (0 where the diagonal is missing or zero); setup-time helper for the
+    zero-initial-guess Jacobi sweep.  Duplicate diagonal entries are summed like in the sweep."""
+    n = A.shape[0]
+    rows = torch.repeat_interleave(torch.arange(n, device=A.vals.device, dtype=torch.int64),
+                                   (A.rowptr[1:] - A.rowptr[:-1]).long())
+    on_diag = A.colidx.long() == rows
+    d = torch.zeros(n, dtype=F64, device=A.vals.device)
+    d.index_add_(0, rows[on_diag], A.vals[on_diag])
+    return torch.where(d != 0, 1.0 / d, torch.zeros_like(d))
+
+
 def copy(src, dst):
     _vec_ok(src, dst)
     check(_lib.lib().lmg_copy(dst.numel(), _p(src), _p(dst), _s()), "lmg_copy")

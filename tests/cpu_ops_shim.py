@@ -63,6 +63,13 @@ def axpby(alpha, x, beta, y):
     yy[:] = alpha * _np(x) if beta == 0.0 else alpha * _np(x) + beta * yy
 
 
+def vmul(alpha, x, y, out):
+    _np(out)[:] = alpha * (_np(x) * _np(y))
+
+
+from learnmultigrid_amd.ops import csr_inverse_diagonal  # noqa: E402,F401  (pure torch)
+
+
 def copy(src, dst):
     dst.copy_(src)
 

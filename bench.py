@@ -33,6 +33,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s copy-achievable
 
+# HBM bytes per launch of the fine-level Jacobi sweep from rocprofv3 PMC passes
+# (2 x FETCH_SIZE [gfx950 counts wide reads at half size] + WRITE_SIZE, KB -> B), keyed by
+# (--size, packed?); see profiles/ for the runs these come from.  None = not measured.
+PMC_TRAFFIC = {(4096, False): 1485261824, (4096, True): 672639665}
+
 
 def sweep_bytes(n, nnz):
     """Algorithmic HBM bytes of one sweep (Jacobi or residual) -- SURVEY.md 8(d):
@@ -54,6 +59,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=-1, help="sweep kernel tile variant (-1 = library default)")
     ap.add_argument("--cpu-cycles", type=int, default=2, help="V-cycles timed by the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-packed", action="store_true", help="plain CSR kernels (no packed twin)")
     return ap.parse_args()
 
 
@@ -110,6 +116,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.variant >= 0:
         ops.tune_set("sweep_variant", args.variant)
+    if args.no_packed:
+        ops.set_packed_enabled(False)
 
     m, levels, nu = args.size, args.levels, args.nu
     A, rhs = P.poisson_2d_structured(m)
@@ -193,11 +201,24 @@ def main():
         t_jac = ev0.elapsed_time(ev1) * 1e-3 / reps
     B = sweep_bytes(fine_A.shape[0], fine_A.nnz)
     achieved = B / t_jac / 1e9
-    roofline = {"bound": "hbm", "kernel": "csr_sweep_kernel<MODE_JACOBI> on the fine level",
+    pk = fine_A.packed if ops._PACKED_ENABLED else None
+    # bytes the launch really has to move: the packed twin (lossless re-encoding of the CSR
+    # arrays) + x once + b + output
+    B_stored = (pk.bytes() if pk is not None else fine_A.bytes()) + 24 * fine_A.shape[0]
+    roofline = {"bound": "hbm",
+                "kernel": ("pcsr_sweep_kernel<JACOBI> (packed CSR: colmode %d, valmode %d, %d dictionary values)"
+                           % (pk.colmode, pk.valmode, pk.ndict)) if pk is not None
+                else "csr_sweep_kernel<JACOBI>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": PMC_TRAFFIC.get((args.size, pk is not None)),
                 "algorithmic_bytes_per_launch": B, "avg_launch_ms": t_jac * 1e3,
-                "rows_per_launch": int(fine_A.shape[0])}
+                "rows_per_launch": int(fine_A.shape[0]),
+                "stored_bytes_per_launch": B_stored,
+                "stored_GBps": B_stored / t_jac / 1e9, "stored_frac_of_peak": B_stored / t_jac / 1e9 / HBM_PEAK_GBS,
+                "note": "achieved = ALGORITHMIC CSR bytes (12 nnz + 4(n+1) + 24 n) / launch time; the kernel "
+                        "reads a lossless packed encoding, so HBM traffic (`traffic`, `stored_*`) is lower than "
+                        "the algorithmic bytes and `frac` can exceed what a CSR stream could reach"}
     cyc_bytes, coarse_bytes = H.cycle_bytes(nu) if args.mode == "vcycle" and world == 1 else (None, None)
     if world > 1 or force_dist:
         out_extra = {"distributed_levels": D.n_dist, "rows_per_rank_fine": n_loc_fine,
@@ -219,7 +240,8 @@ def main():
                       "hipgraph": (not args.no_graph) and world == 1 and not force_dist and args.mode == "vcycle",
                       "level_sizes": [int(s) for s in P.level_sizes(m + 1, levels)],
                       "partition": "row blocks of grid lines over %d rank(s)" % world,
-                      "sweep_variant": ops.tune_get("sweep_variant")},
+                      "sweep_variant": ops.tune_get("sweep_variant"),
+                      "packed_csr": not args.no_packed},
            "setup_s": setup_s, "roofline": roofline}
     out["config"].update(out_extra)
     if cyc_bytes is not None:

@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblmg_hip.so")
+# LMG_LIB_PATH selects another build of the same ABI (A/B runs of two kernel versions)
+LIB_PATH = os.environ.get("LMG_LIB_PATH") or os.path.join(_HERE, "liblmg_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _c = ctypes

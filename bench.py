@@ -222,7 +222,7 @@ def main():
     cyc_bytes, coarse_bytes = H.cycle_bytes(nu) if args.mode == "vcycle" and world == 1 else (None, None)
     if world > 1 or force_dist:
         out_extra = {"distributed_levels": D.n_dist, "rows_per_rank_fine": n_loc_fine,
-                     "halo_values_fine": int(D.dl[0].ghost.numel())}
+                     "halo_values_fine": D.dl[0].n_lo + D.dl[0].n_hi}
     else:
         out_extra = {}
 

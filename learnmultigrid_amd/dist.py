@@ -57,7 +57,25 @@ def _rows(M, lo, hi):
 
 
 class _DLevel:
-    pass
+    """One distributed level on this rank.  Vector layout (length n_tot):
+        [ghosts below lo | owned rows lo..hi | ghosts above hi]      (all in global order)
+    Local matrices have n_tot rows too -- ghost rows are EMPTY -- so row index == column index
+    on the diagonal (the kernels find the diagonal that way), every kernel takes whole
+    vectors, and local column indices grow with the global ones (tile column spans stay small:
+    the packed 16-bit column encoding keeps working)."""
+
+    def to_local(self, c):
+        c = c.long()
+        below = torch.searchsorted(self.ghost_lo, c)
+        above = torch.searchsorted(self.ghost_hi, c)
+        return torch.where(c < self.lo, below,
+                           torch.where(c < self.hi, c - self.lo + self.n_lo, self.n_lo + self.n_own + above))
+
+    def embed_rows(self, rp_owned):
+        """rowptr of the owned rows -> rowptr over the n_tot layout rows (ghost rows empty)."""
+        nnz = rp_owned[-1:]
+        return torch.cat([torch.zeros(self.n_lo, dtype=I32, device=rp_owned.device), rp_owned,
+                          nnz.expand(self.n_hi)]).contiguous()
 
 
 class DistributedVCycle:
@@ -107,7 +125,6 @@ class DistributedVCycle:
                 cuts[0] = 0
             self.bounds.append([int(c) for c in cuts])
         # ---- local slices + ghost sets ---------------------------------------------------------
-        self.dl = []
         raw = []
         for l in range(self.n_dist):
             lo, hi = self.bounds[l][self.rank], self.bounds[l][self.rank + 1]
@@ -125,46 +142,60 @@ class DistributedVCycle:
             ghosts.append(torch.unique(out))           # sorted
         gathered = [None] * self.world
         dist.all_gather_object(gathered, [g.cpu().numpy() for g in ghosts], group=group)
+        self.dl = []
         for l in range(self.n_dist):
             d = _DLevel()
             lo, hi = self.bounds[l][self.rank], self.bounds[l][self.rank + 1]
             d.lo, d.hi, d.n_own = lo, hi, hi - lo
-            d.ghost = ghosts[l]
-            d.n_tot = d.n_own + int(d.ghost.numel())
-            d.A = self._localise(raw[l]["A"], d, d.n_own)
-            nxt_rows = self.bounds[l + 1][self.rank + 1] - self.bounds[l + 1][self.rank]
-            d.R = self._localise(raw[l]["R"], d, nxt_rows)
-            d.P_raw = raw[l]["P"]
-            # exchange plan: recv segments are contiguous (ghosts sorted, owners contiguous)
-            gb = torch.tensor(self.bounds[l], device=d.ghost.device)
-            owner = torch.searchsorted(gb, d.ghost, right=True) - 1
+            g = ghosts[l]
+            d.ghost_lo, d.ghost_hi = g[g < lo].contiguous(), g[g >= hi].contiguous()
+            d.n_lo, d.n_hi = int(d.ghost_lo.numel()), int(d.ghost_hi.numel())
+            d.n_tot = d.n_lo + d.n_own + d.n_hi
+            d.own = slice(d.n_lo, d.n_lo + d.n_own)
+            # exchange plan: per source rank one contiguous ghost segment (ghosts are sorted and
+            # ownership is contiguous)
+            gb = torch.tensor(self.bounds[l], device=g.device)
             d.recv = []
-            for q in torch.unique(owner).tolist():
-                idx = torch.nonzero(owner == q).flatten()
-                d.recv.append((int(q), d.n_own + int(idx[0]), int(idx.numel())))
+            for part, base in ((d.ghost_lo, 0), (d.ghost_hi, d.n_lo + d.n_own)):
+                if part.numel() == 0:
+                    continue
+                owner = torch.searchsorted(gb, part, right=True) - 1
+                for q in torch.unique(owner).tolist():
+                    idx = torch.nonzero(owner == q).flatten()
+                    d.recv.append((int(q), base + int(idx[0]), int(idx.numel())))
             d.send = []
             for q in range(self.world):
                 if q == self.rank:
                     continue
                 want = gathered[q][l]
-                mine = want[(want >= lo) & (want < hi)] - lo
+                mine = want[(want >= lo) & (want < hi)] - lo + d.n_lo
                 if mine.size:
                     d.send.append((q, torch.from_numpy(mine.astype(np.int32)).to(self.device),
                                    torch.empty(mine.size, dtype=F64, device=self.device)))
             for name in ("x", "b", "r", "tmp"):
                 setattr(d, name, torch.zeros(d.n_tot, dtype=F64, device=self.device))
-            d.dinv = self.ops.csr_inverse_diagonal(d.A)
             self.dl.append(d)
-        # P of level l acts on level l+1 vectors: distributed layout or the full replicated vector
+        # ---- local operators in the level layouts -------------------------------------------------
         for l in range(self.n_dist):
             d = self.dl[l]
-            ncoarse = full.levels[l + 1].n
+            rp, ci, va = raw[l]["A"]
+            d.A = DeviceCSR(d.embed_rows(rp), d.to_local(ci).to(I32).contiguous(), va.contiguous(),
+                            (d.n_tot, d.n_tot))
+            d.dinv = self.ops.csr_inverse_diagonal(d.A)
+            rp, ci, va = raw[l]["R"]                      # rows: level l+1, columns: level l
+            rp_p, ci_p, va_p = raw[l]["P"]                # rows: level l,   columns: level l+1
             if l + 1 < self.n_dist:
-                d.P = self._localise(d.P_raw, self.dl[l + 1], d.n_own)
-            else:
-                rp, ci, va = d.P_raw
-                d.P = DeviceCSR(rp, ci.contiguous(), va.contiguous(), (d.n_own, ncoarse))
-            del d.P_raw
+                nxt = self.dl[l + 1]
+                d.R = DeviceCSR(nxt.embed_rows(rp), d.to_local(ci).to(I32).contiguous(), va.contiguous(),
+                                (nxt.n_tot, d.n_tot))
+                d.P = DeviceCSR(d.embed_rows(rp_p), nxt.to_local(ci_p).to(I32).contiguous(),
+                                va_p.contiguous(), (d.n_tot, nxt.n_tot))
+            else:                                         # next level is replicated on every rank
+                nrows = self.bounds[l + 1][self.rank + 1] - self.bounds[l + 1][self.rank]
+                d.R = DeviceCSR(rp.contiguous(), d.to_local(ci).to(I32).contiguous(), va.contiguous(),
+                                (nrows, d.n_tot))
+                d.P = DeviceCSR(d.embed_rows(rp_p), ci_p.contiguous(), va_p.contiguous(),
+                                (d.n_tot, full.levels[l + 1].n))
         if getattr(full, "use_packed", False):
             for d in self.dl:
                 for M in (d.A, d.R, d.P):
@@ -178,7 +209,7 @@ class DistributedVCycle:
         idx = np.concatenate([np.arange(cb[p + 1] - cb[p]) + p * self.ag_max for p in range(self.world)])
         self.ag_index = torch.from_numpy(idx.astype(np.int32)).to(self.device)
         self.ag_rows = cb[self.rank + 1] - cb[self.rank]
-        self.partials = torch.empty(max(1024, self.ops.partials_count(self.dl[0].n_own)), dtype=F64,
+        self.partials = torch.empty(max(1024, self.ops.partials_count(self.dl[0].n_tot)), dtype=F64,
                                     device=self.device)
         self.norm2 = torch.zeros(1, dtype=F64, device=self.device)
 
@@ -203,16 +234,6 @@ class DistributedVCycle:
         anchor = torch.where(anchor == 2 ** 62, torch.zeros_like(anchor), anchor)   # empty rows
         return anchor
 
-    def _localise(self, raw, d, nrows):
-        """Global column ids -> level layout [owned | ghosts]; entry order is preserved."""
-        rp, ci, va = raw
-        c = ci.long()
-        owned = (c >= d.lo) & (c < d.hi)
-        gpos = torch.searchsorted(d.ghost, c.clamp(min=0))
-        gpos = gpos.clamp(max=max(int(d.ghost.numel()) - 1, 0))
-        local = torch.where(owned, c - d.lo, d.n_own + gpos)
-        return DeviceCSR(rp.contiguous(), local.to(I32).contiguous(), va.contiguous(), (nrows, d.n_tot))
-
     # ---- communication -----------------------------------------------------------------------------
     def exchange(self, d, vec):
         """Fill the ghost segment of `vec` (layout of level d) from the owning ranks."""
@@ -230,19 +251,19 @@ class DistributedVCycle:
     def set_rhs(self, rhs):
         d = self.dl[0]
         full = torch.from_numpy(np.ascontiguousarray(np.asarray(rhs, dtype=np.float64).reshape(-1)))
-        d.b[:d.n_own].copy_(full[d.lo:d.hi])
-        d.b[d.n_own:].zero_()
+        d.b.zero_()                                   # ghost rows are empty rows: their rhs is 0
+        d.b[d.own].copy_(full[d.lo:d.hi])
 
     def set_x(self, x):
         d = self.dl[0]
         full = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1)))
-        d.x[:d.n_own].copy_(full[d.lo:d.hi])
+        d.x[d.own].copy_(full[d.lo:d.hi])
 
     def gather_solution(self):
         """Full fine-level iterate on every rank (host array); test / output helper."""
         d = self.dl[0]
         parts = [None] * self.world
-        dist.all_gather_object(parts, d.x[:d.n_own].cpu().numpy(), group=self.group)
+        dist.all_gather_object(parts, d.x[d.own].cpu().numpy(), group=self.group)
         return np.concatenate(parts)
 
     # ---- the cycle ---------------------------------------------------------------------------------------
@@ -250,7 +271,7 @@ class DistributedVCycle:
         o = self.ops
         if x_is_zero and steps > 0:
             # first sweep from zeros: x = omega * (D^-1 b), no halo needed
-            o.vmul(omega, d.dinv, d.b[:d.n_own], d.tmp[:d.n_own])
+            o.vmul(omega, d.dinv, d.b, d.tmp)
             d.x, d.tmp = d.tmp, d.x
             steps -= 1
         elif x_is_zero:
@@ -272,10 +293,10 @@ class DistributedVCycle:
         self.exchange(d, d.r)
         if l + 1 < self.n_dist:
             nxt = self.dl[l + 1]
-            o.csr_spmv(d.R, d.r, nxt.b[:nxt.n_own], 1.0, 0.0)
+            o.csr_spmv(d.R, d.r, nxt.b, 1.0, 0.0)
             self.cycle(smoother, steps, omega, l + 1, x_is_zero=True)
             self.exchange(nxt, nxt.x)
-            o.csr_spmv(d.P, nxt.x, d.x[:d.n_own], 1.0, 1.0)
+            o.csr_spmv(d.P, nxt.x, d.x, 1.0, 1.0)
         else:
             fl = self.full.levels[l + 1]
             o.csr_spmv(d.R, d.r, self.ag_send[:self.ag_rows], 1.0, 0.0)
@@ -285,7 +306,7 @@ class DistributedVCycle:
                 self.full.coarse_solve()
             else:
                 self.full.cycle(smoother, steps, omega, l=l + 1, x_is_zero=True)
-            o.csr_spmv(d.P, fl.x, d.x[:d.n_own], 1.0, 1.0)
+            o.csr_spmv(d.P, fl.x, d.x, 1.0, 1.0)
         self._smooth(d, steps, omega)
 
     def residual_norm(self):

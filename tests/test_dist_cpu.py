@@ -63,7 +63,7 @@ def _worker(rank, world, port, m, levels, replicate_below, out_dir):
                 "n_dist": D.n_dist,
                 "cuts_on_lines": all(c % sd == 0 for l, sd in enumerate(P.level_sizes(side, D.n_dist + 1))
                                      for c in D.bounds[l]),
-                "ghosts": [int(d.ghost.numel()) for d in D.dl],
+                "ghosts": [d.n_lo + d.n_hi for d in D.dl],
                 "neighbours": [sorted(q for q, _o, _c in d.recv) for d in D.dl]}
         with pytest.raises(ValueError):
             D.cycle("GaussSeidel", 1, 1.0)

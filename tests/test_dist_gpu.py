@@ -39,7 +39,7 @@ def test_world1_nccl_path_matches_single_gpu_bitwise():
             for _ in range(4):
                 D.cycle("Jacobi", 3, 0.8)
                 norms.append(D.residual_norm())
-            x = D.dl[0].x[:D.dl[0].n_own].cpu().numpy()
+            x = D.dl[0].x[D.dl[0].own].cpu().numpy()
         H = Hierarchy(A, hier, "cuda:0")
         H.levels[0].b.copy_(torch.from_numpy(rhs.ravel().copy()).to("cuda:0"))
         with torch.cuda.stream(H.stream):

@@ -159,7 +159,9 @@ int lmg_dense_gemv_blockdiag(int64_t nblocks, int64_t bs, const double *d_M, con
  *   2. lmg_spgemm_symbolic  : d_c_rownnz[i] = nnz(C_i)            (needs step 1)
  *      -- caller turns d_c_rownnz into d_c_rowptr with lmg_exclusive_scan_i32 --
  *   3. lmg_spgemm_numeric   : fills d_c_colidx / d_c_vals.
- * Rows whose product count exceeds LMG_SPGEMM_MAX_ROW_PRODUCTS return LMG_ERR_CAPACITY. */
+ * Rows whose product count exceeds LMG_SPGEMM_MAX_ROW_PRODUCTS are skipped by steps 2 and 3
+ * and must be handled by lmg_spgemm_long_rows (same results, dense accumulator in global
+ * scratch: nsets x b_cols doubles and int32 marks, marks zero-initialised by the caller). */
 #define LMG_SPGEMM_MAX_ROW_PRODUCTS 8192
 int lmg_spgemm_count(int64_t a_rows, const int32_t *d_a_rowptr, const int32_t *d_a_colidx,
                      const int32_t *d_b_rowptr, int32_t *d_row_products, int32_t *d_max_products,
@@ -174,6 +176,12 @@ int lmg_spgemm_numeric(int64_t a_rows, const int32_t *d_a_rowptr, const int32_t 
                        const int32_t *d_row_products, int32_t max_products,
                        const int32_t *d_c_rowptr, int32_t *d_c_colidx, double *d_c_vals,
                        void *stream);
+int lmg_spgemm_long_rows(int numeric, int64_t nlong, const int32_t *d_long_rows,
+                         const int32_t *d_a_rowptr, const int32_t *d_a_colidx, const double *d_a_vals,
+                         const int32_t *d_b_rowptr, const int32_t *d_b_colidx, const double *d_b_vals,
+                         int64_t b_cols, int32_t nsets, double *d_scratch_val, int32_t *d_scratch_mark,
+                         int32_t *d_c_rownnz, const int32_t *d_c_rowptr, int32_t *d_c_colidx,
+                         double *d_c_vals, void *stream);
 /* out[0] = 0, out[i+1] = in[0] + ... + in[i]  (n inputs, n+1 outputs).
  * d_scratch holds lmg_scan_scratch_count(n) int32 values. */
 int64_t lmg_scan_scratch_count(int64_t n);

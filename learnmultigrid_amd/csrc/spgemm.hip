@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(BLOCK) spgemm_row_kernel(
             if (!NUMERIC && threadIdx.x == 0) c_rownnz[row] = 0;
             continue;
         }
-        if (np > CAP) continue;   // rejected on the host side; never reached
+        if (np > CAP) continue;   // long row: handled by spgemm_long_row_kernel
         const int a_s = Ap[row], a_e = Ap[row + 1];
         const int m = next_pow2(np);
         __syncthreads();          // previous row fully consumed
@@ -193,13 +193,68 @@ __global__ void __launch_bounds__(BLOCK) spgemm_row_kernel(
     }
 }
 
+// ---- rows beyond the LDS capacity -----------------------------------------------------------
+// One workgroup per long row with a DENSE accumulator (ncols(B) doubles + marks) in global
+// scratch: the A entries of the row are visited one after the other (workgroup barrier in
+// between) and the entries of each B row in parallel -- a canonical B row has distinct
+// columns, so every c_ik still receives its products in SciPy's order.  The marks are then
+// swept in column order to count (symbolic) or emit (numeric) the sorted row, and cleared.
+// Cost O(products + ncols(B)) per row: meant for the few very long rows of an operator
+// (dense-ish transfer columns), not for the bulk.
+template <bool NUMERIC>
+__global__ void __launch_bounds__(256) spgemm_long_row_kernel(
+    int64_t nlong, const int *long_rows, const int *Ap, const int *Aj, const double *Ax, const int *Bp,
+    const int *Bj, const double *Bx, int64_t b_cols, double *scratch_val, int *scratch_mark,
+    int *c_rownnz, const int *Cp, int *Cj, double *Cx)
+{
+    __shared__ int s_w[256 / LMG_WAVE + 1];
+    double *acc = scratch_val + (int64_t)blockIdx.x * b_cols;
+    int *mark = scratch_mark + (int64_t)blockIdx.x * b_cols;
+    for (int64_t li = blockIdx.x; li < nlong; li += gridDim.x) {
+        const int row = long_rows[li];
+        for (int jj = Ap[row]; jj < Ap[row + 1]; ++jj) {
+            const int j = Aj[jj];
+            const double av = NUMERIC ? Ax[jj] : 0.0;
+            for (int kk = Bp[j] + (int)threadIdx.x; kk < Bp[j + 1]; kk += 256) {
+                const int col = Bj[kk];
+                if (NUMERIC) acc[col] = (mark[col] ? acc[col] : 0.0) + av * Bx[kk];
+                mark[col] = 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        // sweep the marks in column order, 256 columns per step
+        int out = NUMERIC ? Cp[row] : 0;
+        for (int64_t c0 = 0; c0 < b_cols; c0 += 256) {
+            const int64_t c = c0 + threadIdx.x;
+            const int m = (c < b_cols) ? mark[c] : 0;
+            int tot;
+            const int rank = block_excl_scan<256>(m, s_w, &tot);
+            if (m) {
+                if (NUMERIC) {
+                    Cj[out + rank] = (int)c;
+                    Cx[out + rank] = acc[c];
+                }
+                mark[c] = 0;
+            }
+            out += tot;
+        }
+        if (!NUMERIC && threadIdx.x == 0) c_rownnz[row] = out;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
 template <bool NUMERIC>
 int launch_rows(int64_t a_rows, const int *Ap, const int *Aj, const double *Ax, const int *Bp,
                 const int *Bj, const double *Bx, const int *row_products, int max_products,
                 int *c_rownnz, const int *Cp, int *Cj, double *Cx, hipStream_t st)
 {
     if (a_rows == 0) return LMG_OK;
-    if (max_products > LMG_SPGEMM_MAX_ROW_PRODUCTS) return LMG_ERR_CAPACITY;
+    // rows above the LDS capacity are skipped here and done by lmg_spgemm_long_rows
+    if (max_products > LMG_SPGEMM_MAX_ROW_PRODUCTS) max_products = LMG_SPGEMM_MAX_ROW_PRODUCTS;
     int64_t g = a_rows;
     if (max_products <= 128) {
         if (g > 256 * 32) g = 256 * 32;
@@ -253,6 +308,28 @@ int lmg_spgemm_numeric(int64_t a_rows, const int32_t *Ap, const int32_t *Aj, con
     if (a_rows < 0 || !Ap || !Bp || !row_products || !Cp) return LMG_ERR_ARG;
     return launch_rows<true>(a_rows, Ap, Aj, Ax, Bp, Bj, Bx, row_products, max_products, nullptr,
                              Cp, Cj, Cx, lmg_stream(stream));
+}
+
+int lmg_spgemm_long_rows(int numeric, int64_t nlong, const int32_t *long_rows, const int32_t *Ap,
+                         const int32_t *Aj, const double *Ax, const int32_t *Bp, const int32_t *Bj,
+                         const double *Bx, int64_t b_cols, int32_t nsets, double *scratch_val,
+                         int32_t *scratch_mark, int32_t *c_rownnz, const int32_t *Cp, int32_t *Cj,
+                         double *Cx, void *stream)
+{
+    if (nlong < 0 || b_cols < 0 || nsets < 1) return LMG_ERR_ARG;
+    if (nlong == 0) return LMG_OK;
+    if (!long_rows || !Ap || !Aj || !Bp || !Bj || !scratch_mark) return LMG_ERR_ARG;
+    if (numeric && (!Ax || !Bx || !scratch_val || !Cp || !Cj || !Cx)) return LMG_ERR_ARG;
+    if (!numeric && !c_rownnz) return LMG_ERR_ARG;
+    const unsigned grid = (unsigned)(nlong < nsets ? nlong : nsets);
+    if (numeric)
+        hipLaunchKernelGGL(spgemm_long_row_kernel<true>, dim3(grid), dim3(256), 0, lmg_stream(stream), nlong,
+                           long_rows, Ap, Aj, Ax, Bp, Bj, Bx, b_cols, scratch_val, scratch_mark, c_rownnz, Cp, Cj, Cx);
+    else
+        hipLaunchKernelGGL(spgemm_long_row_kernel<false>, dim3(grid), dim3(256), 0, lmg_stream(stream), nlong,
+                           long_rows, Ap, Aj, Ax, Bp, Bj, Bx, b_cols, scratch_val, scratch_mark, c_rownnz, Cp, Cj, Cx);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
 }
 
 }  // extern "C"

@@ -347,9 +347,14 @@ def exclusive_scan_i32(inp, out):
     check(_lib.lib().lmg_exclusive_scan_i32(n, _p(inp), _p(out), _p(sc), _s()), "lmg_exclusive_scan_i32")
 
 
+SPGEMM_MAX_ROW_PRODUCTS = 8192       # LMG_SPGEMM_MAX_ROW_PRODUCTS
+_LONG_ROW_SETS = 32
+
+
 class SpGEMMPlan:
     """Symbolic result of C = A*B (pattern of C + per-row product counts); `numeric`
-    can be re-run when only the values of A or B changed (Galerkin rebuild)."""
+    can be re-run when only the values of A or B changed (Galerkin rebuild).  Rows that
+    need more products than the LDS kernels hold go through lmg_spgemm_long_rows."""
 
     def __init__(self, A, B):
         if A.shape[1] != B.shape[0]:
@@ -363,13 +368,28 @@ class SpGEMMPlan:
         check(L.lmg_spgemm_count(n, _p(A.rowptr), _p(A.colidx), _p(B.rowptr), _p(self.row_products),
                                  _p(mx), _s()), "lmg_spgemm_count")
         self.max_products = int(mx.item())
-        rownnz = torch.empty(max(n, 1), dtype=I32, device=dev)
+        rownnz = torch.zeros(max(n, 1), dtype=I32, device=dev)
         check(L.lmg_spgemm_symbolic(n, _p(A.rowptr), _p(A.colidx), _p(B.rowptr), _p(B.colidx),
                                     _p(self.row_products), self.max_products, _p(rownnz), _s()),
               "lmg_spgemm_symbolic")
+        self.long_rows = None
+        if self.max_products > SPGEMM_MAX_ROW_PRODUCTS:
+            self.long_rows = torch.nonzero(self.row_products[:n] > SPGEMM_MAX_ROW_PRODUCTS).flatten().to(I32)
+            self._long(False, A, B, rownnz, None)
         self.c_rowptr = torch.empty(n + 1, dtype=I32, device=dev)
         exclusive_scan_i32(rownnz[:n], self.c_rowptr)
         self.c_nnz = int(self.c_rowptr[-1].item())
+
+    def _long(self, numeric, A, B, rownnz, out):
+        nsets = min(_LONG_ROW_SETS, int(self.long_rows.numel()))
+        bc = B.shape[1]
+        mark = torch.zeros(nsets * bc, dtype=I32, device=A.device)
+        val = torch.empty(nsets * bc, dtype=F64, device=A.device) if numeric else None
+        check(_lib.lib().lmg_spgemm_long_rows(
+            1 if numeric else 0, self.long_rows.numel(), _p(self.long_rows), _p(A.rowptr), _p(A.colidx),
+            _p(A.vals), _p(B.rowptr), _p(B.colidx), _p(B.vals), bc, nsets, _p(val), _p(mark), _p(rownnz),
+            _p(out.rowptr) if out is not None else None, _p(out.colidx) if out is not None else None,
+            _p(out.vals) if out is not None else None, _s()), "lmg_spgemm_long_rows")
 
     def numeric(self, A, B, out=None):
         dev = A.device
@@ -381,6 +401,8 @@ class SpGEMMPlan:
                                             _p(self.row_products), self.max_products,
                                             _p(out.rowptr), _p(out.colidx), _p(out.vals), _s()),
               "lmg_spgemm_numeric")
+        if self.long_rows is not None:
+            self._long(True, A, B, None, out)
         return out
 
 

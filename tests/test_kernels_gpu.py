@@ -279,14 +279,10 @@ def spgemm_case(name):
 def test_spgemm_matches_scipy_bit_exact(name):
     A, B = (K.as_csr(m) for m in spgemm_case(name))
     dA, dB = ops.DeviceCSR.from_scipy(A, DEV), ops.DeviceCSR.from_scipy(B, DEV)
-    if name == "ragged_sq":
-        # one row needs ~18000 products > LMG_SPGEMM_MAX_ROW_PRODUCTS: refused loudly, never
-        # silently computed elsewhere
-        from learnmultigrid_amd._lib import LmgError
-        with pytest.raises(LmgError):
-            ops.SpGEMMPlan(dA, dB)
-        return
     plan = ops.SpGEMMPlan(dA, dB)
+    if name == "ragged_sq":
+        # one row needs ~18000 products > LMG_SPGEMM_MAX_ROW_PRODUCTS: dense-accumulator path
+        assert plan.max_products > 8192 and plan.long_rows is not None and plan.long_rows.numel() >= 1
     if name == "ragged_medium":
         assert 1024 < plan.max_products <= 8192               # exercises the 256-thread class
     C = plan.numeric(dA, dB).to_scipy()
@@ -314,14 +310,20 @@ def test_spgemm_matches_scipy_bit_exact(name):
     assert abs(C2 - w2).max() == 0.0
 
 
-def test_spgemm_capacity_error_is_loud():
-    n = 200
-    A = sp.csr_matrix(np.ones((1, n)))
-    B = sp.csr_matrix(np.ones((n, 100)))
+def test_spgemm_dense_operands_take_the_long_row_path():
+    """Dense-ish transfer operators (the reference scripts pass dense ndarrays as Q): every row
+    of R*A and (R*A)*P needs far more than 8192 products."""
+    rng = np.random.default_rng(31)
+    A = sp.csr_matrix(rng.standard_normal((40, 300)))
+    B = sp.csr_matrix(rng.standard_normal((300, 150)))
     dA, dB = ops.DeviceCSR.from_scipy(A, DEV), ops.DeviceCSR.from_scipy(B, DEV)
-    from learnmultigrid_amd._lib import LmgError
-    with pytest.raises(LmgError):
-        ops.SpGEMMPlan(dA, dB)
+    plan = ops.SpGEMMPlan(dA, dB)
+    assert plan.long_rows.numel() == 40 and plan.c_nnz == 40 * 150
+    C = plan.numeric(dA, dB).to_scipy()
+    want = sp.csr_matrix(A @ B)
+    want.sort_indices()
+    assert np.array_equal(C.indices, want.indices) and np.array_equal(C.indptr, want.indptr)
+    assert np.array_equal(C.data, want.data)                 # same products, same order
 
 
 def test_graph_capture_replays_a_sweep_sequence():

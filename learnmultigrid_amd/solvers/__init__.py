@@ -2,7 +2,8 @@
 from .Solver import Solver, DirectSolver, IterativeSolver
 from .Jacobi import Jacobi
 from .GaussSeidel import GaussSeidel
+from .CG import CG
 from .Multigrid import Multigrid, GeometricMG, SemiGeometricMG, HierarchyMG
 
-__all__ = ["Solver", "DirectSolver", "IterativeSolver", "Jacobi", "GaussSeidel", "Multigrid",
+__all__ = ["Solver", "DirectSolver", "IterativeSolver", "Jacobi", "GaussSeidel", "CG", "Multigrid",
            "GeometricMG", "SemiGeometricMG", "HierarchyMG"]

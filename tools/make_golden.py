@@ -308,8 +308,39 @@ def g4_structured_2d():
              **coo(A_free, "A_free"), **coo(sp.csr_matrix(A), "A"), **coo(sp.csr_matrix(M), "M"))
 
 
+# ----------------------------------------------------------------------------- G5 / G6
+def g5_saved_files():
+    """Files written by the reference's own save() methods (StiffnessMatrix.py:38-45,
+    LoadVector.py:36-38): fixtures for learnmultigrid_amd/io.py."""
+    def fm1(x):
+        return -1
+    mesh = quiet(Mesh2D, 16)
+    q, dphi, phi = Quadrature2D(3), GradientTriangle(1), FunctionTriangle(1)
+    st = StiffnessMatrix(mesh)
+    quiet(st.compute_stiffness_2d, dphi, q)
+    st.save(os.path.join(OUT, "g5_saved_A"))
+    lv = LoadVector(mesh)
+    quiet(lv.compute_rhs_2d, LoadFunction(fm1), phi, q)
+    lv.save(os.path.join(OUT, "g5_saved_rhs"))
+    print("wrote g5_saved_A.npz / g5_saved_rhs.npy with the reference's save()")
+
+
+def g6_cg():
+    """CG.py needs np.asscalar (removed in NumPy 1.23): shimmed for this run only."""
+    from learn_multigrid.solvers.CG import CG
+    if not hasattr(np, "asscalar"):
+        np.asscalar = lambda a: a.item()
+    _mesh, A, rhs = quiet(poisson_1d, 64)
+    c = quiet(CG, A, rhs)
+    quiet(c.solve, max_iterations=200, error=1e-10)
+    save("g6_cg_ne64", track=c.get_track_res(), iterations=c.get_iterations(), solution=c.get_solution(),
+         rhs=rhs, **coo(A, "A"))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    g5_saved_files()
+    g6_cg()
     rel = g2_gs_crosscheck()
     g1_small_solvers()
     g2_interpolators()

@@ -233,3 +233,56 @@ def jittered_poisson_2d(m, seed=42, jitter=0.25, coeff_sigma=None, coeff_seed=44
     np.add.at(rhs, tri.ravel(), np.repeat(-det / 6.0, 3))
     A, rhs = apply_dirichlet_identity_rows(A, rhs.reshape(-1, 1), boundary)
     return A, rhs
+
+
+def variable_coeff_poisson_2d_structured(m, seed=44, sigma=0.5, coeff=None):
+    """cfg#5 problem: -div(k grad u) with one coefficient per triangle, P1 on the structured
+    triangulation, Dirichlet identity rows, load vector of f == -1 -- built directly as CSR
+    (5-point rows) so that 8193^2 nodes need no 1.2 G-entry COO detour.  The reference has no
+    variable-coefficient assembly (test/thesis_variableCoeff_stiff.py is empty); this is
+    StiffnessMatrix.loc_a_2d (StiffnessMatrix.py:53-59) with each element matrix scaled by
+    k_e, cross-checked against p1_stiffness_2d(coeff=...) in the tests.
+
+    coeff: optional (2*m*m,) array, first the lower-right triangles (k, k+1, k+s+1) of all
+    squares row-major, then the upper-left ones (k, k+s+1, k+s); default exp(sigma*N(0,1))."""
+    s = m + 1
+    n = s * s
+    h = 1.0 / m
+    if coeff is None:
+        coeff = np.exp(sigma * np.random.default_rng(seed).standard_normal(2 * m * m))
+    k1 = np.zeros((m + 1, m + 1))
+    k2 = np.zeros((m + 1, m + 1))
+    k1[:m, :m] = coeff[: m * m].reshape(m, m)          # [j, i]: triangle with legs bottom/right
+    k2[:m, :m] = coeff[m * m:].reshape(m, m)           # [j, i]: triangle with legs left/top
+    # edge weights: a leg shared by two triangles carries -(k_a + k_b)/2, hypotenuses carry 0
+    k2_below = np.zeros((s, s))
+    k2_below[1:, :] = k2[:m, :]                        # square (i, j-1)
+    k1_left = np.zeros((s, s))
+    k1_left[:, 1:] = k1[:, :m]                         # square (i-1, j)
+    w_right = -(k1 + k2_below) / 2.0                   # edge (i,j)-(i+1,j), defined for i < m
+    w_up = -(k2 + k1_left) / 2.0                       # edge (i,j)-(i,j+1), defined for j < m
+    idx = np.arange(n, dtype=np.int64)
+    i, j = idx % s, idx // s
+    boundary = (i == 0) | (i == m) | (j == 0) | (j == m)
+    nnz_row = np.where(boundary, 1, 5).astype(np.int64)
+    rowptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(nnz_row, out=rowptr[1:])
+    nnz = int(rowptr[-1])
+    colidx = np.empty(nnz, dtype=np.int32)
+    vals = np.empty(nnz, dtype=np.float64)
+    b = np.flatnonzero(boundary)
+    colidx[rowptr[b]] = b
+    vals[rowptr[b]] = 1.0
+    it = np.flatnonzero(~boundary)
+    ii, jj = i[it], j[it]
+    wd = w_up[jj - 1, ii]
+    wl = w_right[jj, ii - 1]
+    wr = w_right[jj, ii]
+    wu = w_up[jj, ii]
+    p = rowptr[it]
+    for off, (dc, v) in enumerate(((-s, wd), (-1, wl), (0, -(wd + wl + wr + wu)), (1, wr), (s, wu))):
+        colidx[p + off] = it + dc
+        vals[p + off] = v
+    A = sp.csr_matrix((vals, colidx, rowptr.astype(np.int32)), shape=(n, n))
+    rhs = np.where(boundary, 0.0, -(h * h)).reshape(n, 1)
+    return A, rhs

@@ -295,3 +295,56 @@ def test_multigrid_preconditioned_cg_converges_fast():
     assert pcg.get_iterations() < 15 < plain.get_iterations()
     x_ref = plain.get_solution()
     assert np.linalg.norm(pcg.get_solution() - x_ref) <= 1e-6 * np.linalg.norm(x_ref)
+
+
+def learned_like_hierarchy(side, levels, seed=43):
+    hier = []
+    for l, s in enumerate(P.level_sizes(side, levels)[:-1]):
+        base = sp.kron(P.pseudo_l2_interpolator_1d(s), P.pseudo_l2_interpolator_1d(s)).tocsr()
+        hier.append(P.learned_like(base, seed + l))
+    return hier
+
+
+def test_cfg3_unstructured_like_2M_dof_learned_q_five_levels():
+    """BASELINE config #3: ~2 M DoF triangle mesh (1441^2 jittered nodes, 7-point P1 stiffness),
+    5-level V-cycle with learned-like (row-stochastic, perturbed L2-type) transfer operators."""
+    m, levels = 1440, 5
+    A, rhs = P.jittered_poisson_2d(m, seed=42)
+    assert A.shape[0] == 2076481
+    hier = learned_like_hierarchy(m + 1, levels)
+    kw = dict(levels=levels, smooth_steps=3, max_iterations=4, error=1e-30)
+    ref = oracle_run(A, rhs, hier, smoother="Jacobi", semantics="as_named", omega=0.8, **kw)
+    mg = HierarchyMG(A, rhs.copy(), hier)
+    mg.solve(smoother="Jacobi", smoother_semantics="as_named", omega=0.8, **kw)
+    assert_track(mg.get_track_res(), ref.track_res)
+    assert mg.level_dims == ref.level_dims == [s * s for s in (1441, 721, 361, 181, 91)]
+    ref = oracle_run(A, rhs, hier, smoother="GaussSeidel", semantics="as_shipped", **dict(kw, max_iterations=3))
+    mg = HierarchyMG(A, rhs.copy(), hier)
+    mg.solve(smoother="GaussSeidel", **dict(kw, max_iterations=3))
+    assert_track(mg.get_track_res(), ref.track_res)
+
+
+def test_cfg5_style_variable_coefficient_rebuild_and_solve():
+    """BASELINE config #5 at 1025^2 (the 8193^2 run is tools/run_cfg5.py): variable-coefficient
+    stiffness, learned-like Q, Galerkin rebuild (numeric SpGEMM only) after the coefficients
+    change, then the solve -- against the oracle on the rebuilt problem."""
+    from learnmultigrid_amd.hierarchy import Hierarchy
+    m, levels = 1024, 5
+    A1, rhs = P.variable_coeff_poisson_2d_structured(m, seed=44)
+    A2, _ = P.variable_coeff_poisson_2d_structured(m, seed=45)
+    hier = learned_like_hierarchy(m + 1, levels)
+    H = Hierarchy(A1, hier, "cuda:0")
+    H.rebuild_numeric(torch.from_numpy(A2.data.copy()).to("cuda:0"))
+    fine = H.levels[0]
+    fine.b.copy_(torch.from_numpy(rhs.ravel().copy()).to("cuda:0"))
+    norms = []
+    with torch.cuda.stream(H.stream):
+        for _ in range(4):
+            norms.append(H.residual_norm())
+            H.cycle("Jacobi", 3, 0.8)
+        norms.append(H.residual_norm())
+    ref = oracle_run(A2, rhs, hier, smoother="Jacobi", semantics="as_named", omega=0.8, levels=levels,
+                     smooth_steps=3, max_iterations=5, error=1e-30)
+    want = ref.track_res.ravel()
+    got = np.array(norms)
+    np.testing.assert_allclose(got[1:], want[1:], rtol=1e-10)           # (entry 0 is the sqrt(n) quirk)

@@ -58,6 +58,11 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch kernels from Python instead of replaying a hipGraph")
     ap.add_argument("--variant", type=int, default=-1, help="sweep kernel tile variant (-1 = library default)")
     ap.add_argument("--cpu-cycles", type=int, default=2, help="V-cycles timed by the CPU baseline leg")
+    ap.add_argument("--problem", default="poisson", choices=["poisson", "varcoeff", "jittered"],
+                    help="poisson = cfg#2/#4 (default), varcoeff = cfg#5, jittered = cfg#3 (7-point)")
+    ap.add_argument("--transfer", default="geometric", choices=["geometric", "learned"],
+                    help="learned = row-stochastic perturbed L2-type Q per level (cfg#3/#5)")
+    ap.add_argument("--rebuild", type=int, default=0, help="time this many numeric Galerkin rebuilds (cfg#5)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-packed", action="store_true", help="plain CSR kernels (no packed twin)")
     return ap.parse_args()
@@ -120,8 +125,20 @@ def main():
         ops.set_packed_enabled(False)
 
     m, levels, nu = args.size, args.levels, args.nu
-    A, rhs = P.poisson_2d_structured(m)
-    hier = P.geometric_hierarchy_2d(m + 1, levels)
+    if args.problem == "poisson":
+        A, rhs = P.poisson_2d_structured(m)
+    elif args.problem == "varcoeff":
+        A, rhs = P.variable_coeff_poisson_2d_structured(m, seed=44)
+    else:
+        A, rhs = P.jittered_poisson_2d(m, seed=42)
+    if args.transfer == "geometric":
+        hier = P.geometric_hierarchy_2d(m + 1, levels)
+    else:
+        import scipy.sparse as sp
+        hier = []
+        for li, sz in enumerate(P.level_sizes(m + 1, levels)[:-1]):
+            l2 = P.pseudo_l2_interpolator_1d(sz)
+            hier.append(P.learned_like(sp.kron(l2, l2).tocsr(), 43 + li))
     n, nnz = A.shape[0], A.nnz
 
     def barrier():
@@ -226,11 +243,20 @@ def main():
     else:
         out_extra = {}
 
+    rebuild_ms = None
+    if args.rebuild and world == 1 and not force_dist:
+        newv = fine_A.vals.clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.rebuild):
+            H.rebuild_numeric(newv)
+        torch.cuda.synchronize()
+        rebuild_ms = (time.perf_counter() - t0) / args.rebuild * 1e3
     out = {"metric": "fine-level DoF*sweeps/s, 2-D Poisson V-cycle", "value": value,
            "unit": "DoF*sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "cfg#4: 2-D structured P1 Poisson %dx%d elements (%d DoF, %d nnz, CSR "
+           "config": {"workload": "2-D structured P1 Poisson %dx%d elements (%d DoF, %d nnz, CSR "
                                   "fp64/int32), %d-level V(%d,%d) cycle, weighted Jacobi omega=%.2f, "
                                   "tensor-product geometric transfer, Galerkin RAP by device SpGEMM"
                                   % (m, m, n, nnz, levels, nu, nu, args.omega),
@@ -244,6 +270,10 @@ def main():
                       "packed_csr": not args.no_packed},
            "setup_s": setup_s, "roofline": roofline}
     out["config"].update(out_extra)
+    if rebuild_ms is not None:
+        out["galerkin_rebuild_ms"] = rebuild_ms
+    out["config"]["problem"] = args.problem
+    out["config"]["transfer"] = args.transfer
     if cyc_bytes is not None:
         out["cycle_algorithmic_GBps"] = cyc_bytes / (dt / args.steps) / 1e9
         out["cycle_algorithmic_bytes"] = cyc_bytes

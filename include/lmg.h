@@ -47,7 +47,7 @@ const char *lmg_status_string(int status);
 int lmg_device_count(void);
 
 /* Runtime tuning knobs (kernel variant selection; used by bench.py for A/B runs).
- *   key "pcsr_ju"       : row entries per step of the packed sweeps (0 = auto, 1, 2, 3, 5).
+ *   key "pcsr_ju"       : row entries per step of the packed sweeps (0 = auto, 1, 3, 5).
  *   key "sweep_variant" : tile geometry of the sweep kernels, 0..23 (0 = default: chosen
  *                         per launch from the average row length).                     */
 int lmg_tune_set(const char *key, int value);
@@ -83,7 +83,8 @@ int lmg_csr_spmv(int64_t n_rows, int64_t nnz, const int32_t *d_rowptr, const int
  * PackedCSR shows how), that keeps the entry order -- results are bit-identical to the CSR
  * entry points above -- and moves fewer bytes:
  *   d_rowlen[n]          uint8 row lengths (rows longer than 255 entries: not packable)
- *   d_tile_base[T+1]     int32 entry offset of every tile of lmg_pcsr_tile_rows() (=512) rows
+ *   d_tile_base[T+1]     int32 entry offset of every tile of `tile_rows` rows (512 by default
+ *                        = lmg_pcsr_tile_rows(); 128 or 64 for matrices with long rows)
  *   d_col                colmode 0: uint16 (column - d_tile_colbase[tile]); 1: int32 column
  *   d_val                valmode 0: uint8 index into d_dict (ndict <= 256); 1: uint16 index
  *                        (ndict <= 65536); 2: raw fp64 (d_dict unused)
@@ -92,7 +93,8 @@ int lmg_csr_spmv(int64_t n_rows, int64_t nnz, const int32_t *d_rowptr, const int
  * the argument meaning of lmg_csr_residual_norm2 / lmg_csr_jacobi (alpha = omega) /
  * lmg_csr_spmv.  LMG_ERR_CAPACITY if a tile does not fit the LDS budget (use the CSR path). */
 int lmg_pcsr_tile_rows(void);
-int lmg_pcsr_sweep(int mode, int64_t n, int64_t nnz, int32_t tile_cap, const int32_t *d_tile_base,
+int lmg_pcsr_sweep(int mode, int64_t n, int64_t nnz, int32_t tile_rows, int32_t tile_cap,
+                   const int32_t *d_tile_base,
                    const int32_t *d_tile_colbase, const uint8_t *d_rowlen, const void *d_col,
                    int colmode, const void *d_val, int valmode, const double *d_dict, int32_t ndict,
                    const double *d_x, const double *d_b, double *d_out, double alpha, double beta,

@@ -29,7 +29,7 @@ SIGNATURES = {
     "lmg_csr_jacobi": (_c.c_int, [_i64, _i64, _p, _p, _p, _p, _p, _f64, _p, _p]),
     "lmg_csr_spmv": (_c.c_int, [_i64, _i64, _p, _p, _p, _p, _p, _f64, _f64, _p]),
     "lmg_pcsr_tile_rows": (_c.c_int, []),
-    "lmg_pcsr_sweep": (_c.c_int, [_c.c_int, _i64, _i64, _i32, _p, _p, _p, _p, _c.c_int, _p, _c.c_int, _p, _i32,
+    "lmg_pcsr_sweep": (_c.c_int, [_c.c_int, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _c.c_int, _p, _c.c_int, _p, _i32,
                                   _p, _p, _p, _f64, _f64, _p, _p, _p]),
     "lmg_csr_gs_rows": (_c.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p]),
     "lmg_csr_gs_schedule": (_c.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _c.c_int, _p]),

@@ -29,9 +29,10 @@ enum { MODE_RESIDUAL = 0, MODE_JACOBI = 1, MODE_SPMV = 2 };
 enum { COL16 = 0, COL32 = 1 };
 enum { VAL8 = 0, VAL16 = 1, VAL64 = 2 };
 
-constexpr int kBlock = 128;
-constexpr int kRpt = 4;
-constexpr int kTileRows = kBlock * kRpt;   // 512
+// Tile geometries (threads per workgroup, rows per thread): 512-row tiles for short rows,
+// 128- and 64-row tiles when the rows are long enough that 512 of them would not fit the
+// LDS budget (25-entry rows of L2-type Galerkin operators).  Chosen at pack time.
+constexpr int kDefaultTileRows = 512;
 
 struct PArgs {
     int n;
@@ -39,6 +40,7 @@ struct PArgs {
     int tiles;
     int tiles_per_xcd;
     int cap;                 // LDS capacity in entries (>= largest tile + alignment slack)
+    int tile_rows;           // 512, 128 or 64
     const int *tile_base;    // tiles + 1 entry offsets
     const int *tile_colbase; // tiles
     const unsigned char *rowlen;
@@ -72,6 +74,7 @@ template <> struct ValT<VAL16> { typedef unsigned short type; };
 template <> struct ValT<VAL64> { typedef double type; };
 
 // copy the 16-byte-aligned byte window [lo16, hi) of a global array into LDS, 16 B per lane
+template <int kBlock>
 __device__ __forceinline__ void stage_bytes(const unsigned char *g, long lo16, long hi, unsigned char *s, int t)
 {
     for (long off = lo16 + (long)t * 16; off < hi; off += (long)kBlock * 16)
@@ -80,9 +83,11 @@ __device__ __forceinline__ void stage_bytes(const unsigned char *g, long lo16, l
 
 // JU = entries of each row handled per step (JU x 4 independent gathers in flight per thread)
 // EXP (timing experiments only, wrong results): 1 = no x gathers, 2 = no gathers and no staging
-template <int MODE, int COLMODE, int VALMODE, int JU, int EXP = 0>
+template <int MODE, int COLMODE, int VALMODE, int JU, int EXP = 0, int kBlock = 128, int kRpt = 4>
 __global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
 {
+    constexpr int kTileRows = kBlock * kRpt;
+    constexpr int NW = kBlock / LMG_WAVE;
     typedef typename ColT<COLMODE>::type col_t;
     typedef typename ValT<VALMODE>::type val_t;
     constexpr int CPER = 16 / (int)sizeof(col_t);   // entries per 16-byte chunk
@@ -97,7 +102,7 @@ __global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
     unsigned char *s_colb = smem + dict_bytes;
     unsigned char *s_valb = s_colb + col_bytes;
     int *s_scan = reinterpret_cast<int *>(s_valb + val_bytes);
-    double *s_red = reinterpret_cast<double *>(s_scan + 8);
+    double *s_red = reinterpret_cast<double *>(s_scan + 8);     // s_scan: kRpt*NW <= 8 ints
     const col_t *s_col = reinterpret_cast<const col_t *>(s_colb);
     const val_t *s_val = reinterpret_cast<const val_t *>(s_valb);
 
@@ -135,15 +140,15 @@ __global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
 #pragma unroll
         for (int k = 0; k < kRpt; ++k) {
             incl[k] = wave_incl_scan_i(len[k], lane);
-            if (lane == 63) s_scan[k * 2 + wave] = incl[k];
+            if (lane == 63) s_scan[k * NW + wave] = incl[k];
         }
         // ---- stage the packed streams (still packed) ---------------------------------------
         const int ac = base & ~(CPER - 1);          // first staged entry of each stream
         const int av = base & ~(VPER - 1);
         if (EXP != 2) {
-            stage_bytes(reinterpret_cast<const unsigned char *>(a.col), (long)ac * sizeof(col_t),
+            stage_bytes<kBlock>(reinterpret_cast<const unsigned char *>(a.col), (long)ac * sizeof(col_t),
                         (long)end * sizeof(col_t), s_colb, t);
-            stage_bytes(reinterpret_cast<const unsigned char *>(a.val), (long)av * sizeof(val_t),
+            stage_bytes<kBlock>(reinterpret_cast<const unsigned char *>(a.val), (long)av * sizeof(val_t),
                         (long)end * sizeof(val_t), s_valb, t);
         }
         __syncthreads();
@@ -155,8 +160,12 @@ __global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
 #pragma unroll
             for (int k = 0; k < kRpt; ++k) {
                 int before = run;
-                if (wave == 1) before += s_scan[k * 2];
-                run += s_scan[k * 2] + s_scan[k * 2 + 1];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const int sw = s_scan[k * NW + w];
+                    if (w < wave) before += sw;
+                    run += sw;
+                }
                 rs[k] = base + before + incl[k] - len[k];
             }
         }
@@ -278,6 +287,8 @@ int g_pcsr_ju = 0;      // 0 = pick from the average row length; 1, 2, 3, 5 = fo
 
 template <int MODE, int COLMODE, int VALMODE, int JU>
 int launch_ju(PArgs a, hipStream_t st);
+template <int MODE, int COLMODE, int VALMODE, int JU, int kBlock, int kRpt>
+int launch_geo(PArgs a, hipStream_t st);
 
 template <int MODE, int COLMODE, int VALMODE>
 int launch(PArgs a, hipStream_t st)
@@ -288,10 +299,11 @@ int launch(PArgs a, hipStream_t st)
         // footprint (JU 1); ~9-entry rows want 3 steps of 3, or 2 steps of 5 when the gathers
         // go to a much longer vector (restriction: SpMV mode)
         const double avg = (double)a.nnz / (double)a.n;
-        ju = avg <= 6.0 ? 1 : (MODE == MODE_SPMV ? 5 : 3);
+        ju = avg <= 6.0 ? 1 : ((MODE == MODE_SPMV || avg > 12.0) ? 5 : 3);
     }
     if (ju == 101 || ju == 102) {
-        if (COLMODE != COL16 || VALMODE != VAL8) return LMG_ERR_ARG;
+        if (COLMODE != COL16 || VALMODE != VAL8 || a.tile_rows != 512) return LMG_ERR_ARG;
+        constexpr int kBlock = 128;
         const int lds = lds_bytes(a.cap, COLMODE, VALMODE);
         int64_t grid = 256 * 10;
         if (grid > (int64_t)a.tiles_per_xcd * 8) grid = (int64_t)a.tiles_per_xcd * 8;
@@ -302,9 +314,9 @@ int launch(PArgs a, hipStream_t st)
         LMG_CHECK_LAUNCH();
         return LMG_OK;
     }
+    if (a.tile_rows != 512 && ju < 3) ju = 3;
     switch (ju) {
     case 1: return launch_ju<MODE, COLMODE, VALMODE, 1>(a, st);
-    case 2: return launch_ju<MODE, COLMODE, VALMODE, 2>(a, st);
     case 5: return launch_ju<MODE, COLMODE, VALMODE, 5>(a, st);
     default: return launch_ju<MODE, COLMODE, VALMODE, 3>(a, st);
     }
@@ -313,17 +325,32 @@ int launch(PArgs a, hipStream_t st)
 template <int MODE, int COLMODE, int VALMODE, int JU>
 int launch_ju(PArgs a, hipStream_t st)
 {
+    // instantiated combinations: 512-row tiles with JU 1/3/5 and every encoding; 128- and
+    // 64-row tiles (long rows) with JU 3/5 and VAL8 / VAL64 only
+    if (a.tile_rows == 512) return launch_geo<MODE, COLMODE, VALMODE, JU, 128, 4>(a, st);
+    if constexpr (JU >= 3 && VALMODE != VAL16) {
+        if (a.tile_rows == 128) return launch_geo<MODE, COLMODE, VALMODE, JU, 128, 1>(a, st);
+        if (a.tile_rows == 64) return launch_geo<MODE, COLMODE, VALMODE, JU, 64, 1>(a, st);
+    }
+    return LMG_ERR_ARG;
+}
+
+template <int MODE, int COLMODE, int VALMODE, int JU, int kBlock, int kRpt>
+int launch_geo(PArgs a, hipStream_t st)
+{
     const int lds = lds_bytes(a.cap, COLMODE, VALMODE);
     if (lds > kMaxLds) return LMG_ERR_CAPACITY;
     // persistent grid: exactly as many workgroups per CU as registers + LDS admit
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pcsr_sweep_kernel<MODE, COLMODE, VALMODE, JU>,
-                                                     kBlock, (size_t)lds) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &per_cu, pcsr_sweep_kernel<MODE, COLMODE, VALMODE, JU, 0, kBlock, kRpt>, kBlock, (size_t)lds) != hipSuccess ||
+        per_cu < 1)
         per_cu = 4;
-    if (per_cu > 16) per_cu = 16;
+    if (per_cu > 32) per_cu = 32;
     int64_t grid = 256 * (int64_t)per_cu;
     if (grid > (int64_t)a.tiles_per_xcd * 8) grid = (int64_t)a.tiles_per_xcd * 8;
-    hipLaunchKernelGGL((pcsr_sweep_kernel<MODE, COLMODE, VALMODE, JU>), dim3((unsigned)grid), dim3(kBlock), lds, st, a);
+    hipLaunchKernelGGL((pcsr_sweep_kernel<MODE, COLMODE, VALMODE, JU, 0, kBlock, kRpt>), dim3((unsigned)grid),
+                       dim3(kBlock), lds, st, a);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }
@@ -347,7 +374,7 @@ int dispatch(PArgs a, int colmode, int valmode, hipStream_t st)
 
 int lmg_pcsr_tune_set(int ju)
 {
-    if (ju != 0 && ju != 1 && ju != 2 && ju != 3 && ju != 5 && ju != 101 && ju != 102) return LMG_ERR_ARG;
+    if (ju != 0 && ju != 1 && ju != 3 && ju != 5 && ju != 101 && ju != 102) return LMG_ERR_ARG;
     g_pcsr_ju = ju;
     return LMG_OK;
 }
@@ -355,15 +382,16 @@ int lmg_pcsr_tune_get(void) { return g_pcsr_ju; }
 
 extern "C" {
 
-int lmg_pcsr_tile_rows(void) { return kTileRows; }
+int lmg_pcsr_tile_rows(void) { return kDefaultTileRows; }
 
-int lmg_pcsr_sweep(int mode, int64_t n, int64_t nnz, int32_t tile_cap, const int32_t *tile_base,
+int lmg_pcsr_sweep(int mode, int64_t n, int64_t nnz, int32_t tile_rows, int32_t tile_cap, const int32_t *tile_base,
                    const int32_t *tile_colbase, const uint8_t *rowlen, const void *col, int colmode,
                    const void *val, int valmode, const double *dict, int32_t ndict, const double *x,
                    const double *b, double *out, double alpha, double beta, double *partials,
                    double *norm2, void *stream)
 {
     if (n < 0 || nnz < 0 || n >= INT32_MAX || nnz >= INT32_MAX - 65536 || tile_cap < 0) return LMG_ERR_ARG;
+    if (tile_rows != 512 && tile_rows != 128 && tile_rows != 64) return LMG_ERR_ARG;
     if (n == 0) return LMG_OK;
     if (!tile_base || !rowlen || (nnz > 0 && (!col || !val || !x))) return LMG_ERR_ARG;
     if (colmode == COL16 && !tile_colbase) return LMG_ERR_ARG;
@@ -382,7 +410,8 @@ int lmg_pcsr_sweep(int mode, int64_t n, int64_t nnz, int32_t tile_cap, const int
     PArgs a;
     a.n = (int)n;
     a.nnz = (int)nnz;
-    a.tiles = (int)((n + kTileRows - 1) / kTileRows);
+    a.tile_rows = tile_rows;
+    a.tiles = (int)((n + tile_rows - 1) / tile_rows);
     a.tiles_per_xcd = (a.tiles + 7) / 8;
     a.cap = tile_cap + 32;
     a.tile_base = tile_base;

@@ -93,7 +93,7 @@ class PackedCSR:
     distinct values -- compared BITWISE, so -0.0 / NaN payloads survive.  Built with torch
     ops at setup (format conversion, like SciPy's csc -> csr); the sweeps are the HIP kernel."""
 
-    __slots__ = ("n", "nnz", "shape", "tile_cap", "tile_base", "tile_colbase", "rowlen", "col",
+    __slots__ = ("n", "nnz", "shape", "tile_rows", "tile_cap", "tile_base", "tile_colbase", "rowlen", "col",
                  "colmode", "val", "valmode", "dict", "ndict", "bytes_")
 
     @staticmethod
@@ -109,16 +109,30 @@ class PackedCSR:
         if n == 0 or nnz == 0:
             return None
         dev = A.vals.device
-        T = int(_lib.lib().lmg_pcsr_tile_rows())
         rowlen = (A.rowptr[1:] - A.rowptr[:-1])
         if int(rowlen.max()) > 255 or int(rowlen.min()) < 0:
             return None
+        # value encoding first: it decides how many bytes an entry occupies in LDS
+        bits = A.vals.view(torch.int64)
+        uniq = torch.unique(bits)
+        ndict = int(uniq.numel())
+        # tile height: 512 rows unless the rows are so long that a tile would not leave room for
+        # several workgroups per CU (budget ~20 KB of LDS per tile); long-row tiles only exist
+        # for the VAL8 / VAL64 encodings
+        avg = nnz / n
+        T = int(_lib.lib().lmg_pcsr_tile_rows())
+        bpe = 2 + (1 if ndict <= 256 else (2 if ndict <= 65536 else 8))
+        if T * avg * bpe > 20480:
+            T = 128 if 128 * avg * (2 + (1 if ndict <= 256 else 8)) <= 20480 else 64
+            if 256 < ndict <= 65536:
+                ndict = 1 << 30                    # force raw values
         ntile = (n + T - 1) // T
         tb = A.rowptr[0:n:T]
         tile_base = torch.cat([tb, A.rowptr[n:n + 1]]).contiguous()
         tile_nnz = tile_base[1:] - tile_base[:-1]
         self = cls()
         self.n, self.nnz, self.shape = n, nnz, A.shape
+        self.tile_rows = T
         self.tile_cap = int(tile_nnz.max())
         self.tile_base = tile_base
         self.rowlen = rowlen.to(torch.uint8).contiguous()
@@ -139,9 +153,7 @@ class PackedCSR:
             self.tile_colbase = cmin.contiguous()
             self.col = cls._padded(A.colidx)
         del tile_of_entry
-        bits = A.vals.view(torch.int64)
-        uniq = torch.unique(bits)
-        self.ndict = int(uniq.numel())
+        self.ndict = ndict
         if self.ndict <= 256:
             self.valmode = 0
             self.val = cls._padded(torch.searchsorted(uniq, bits).to(torch.uint8))
@@ -173,7 +185,7 @@ def set_packed_enabled(flag):
 
 
 def _pcsr(mode, P, x, b, out, alpha, beta, partials, norm2):
-    rc = _lib.lib().lmg_pcsr_sweep(mode, P.n, P.nnz, P.tile_cap, _p(P.tile_base), _p(P.tile_colbase),
+    rc = _lib.lib().lmg_pcsr_sweep(mode, P.n, P.nnz, P.tile_rows, P.tile_cap, _p(P.tile_base), _p(P.tile_colbase),
                                    _p(P.rowlen), _p(P.col), P.colmode, _p(P.val), P.valmode,
                                    _p(P.dict), P.ndict, _p(x), _p(b), _p(out), float(alpha), float(beta),
                                    _p(partials), _p(norm2), _s())

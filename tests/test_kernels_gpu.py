@@ -388,6 +388,16 @@ def packed_case(name):
         v = rng.standard_normal(k) if name.startswith("val64") else rng.integers(1, 3000, k).astype(np.float64)
         A = sp.coo_matrix((v, (r, c)), shape=(n, n)).tocsr() + sp.identity(n) * 3.0
         return K.as_csr(A)
+    if name in ("val64_longrows_l2_galerkin", "val8_longrows_l2_galerkin"):
+        A2, _ = P.poisson_2d_structured(256)
+        l2 = P.pseudo_l2_interpolator_1d(257)
+        Q = sp.kron(l2, l2).tocsr()
+        if name.startswith("val64"):
+            Q = P.learned_like(Q, 43)
+        else:
+            # exactly representable weights -> few distinct Galerkin values (dictionary encoding)
+            Q.data = np.round(Q.data * 64) / 64
+        return K.as_csr(sp.csr_matrix(Q.T @ A2 @ Q))
     if name == "galerkin_9pt":
         A2, _ = P.poisson_2d_structured(256)
         Pm = P.tensor_interpolator_2d(257)
@@ -395,7 +405,7 @@ def packed_case(name):
     raise KeyError(name)
 
 
-PACKED = ["val8_col16_poisson2d_513", "val8_col16_prolong", "val8_col16_restrict", "val8_col16_poisson1d",
+PACKED = ["val64_longrows_l2_galerkin", "val8_longrows_l2_galerkin", "val8_col16_poisson2d_513", "val8_col16_prolong", "val8_col16_restrict", "val8_col16_poisson1d",
           "val16_col16_ragged", "val64_col16_jittered", "val64_col32_random", "val16_col32_random",
           "galerkin_9pt"]
 
@@ -418,6 +428,12 @@ def test_packed_sweeps_bit_exact(name):
     if "_col32_" in name:
         assert Pk.colmode == 1
     assert Pk.bytes() < dA.bytes()
+    if "longrows" in name:
+        assert Pk.tile_rows in (64, 128) and np.diff(A.indptr).max() >= 20
+    elif name.startswith("val8"):
+        assert Pk.tile_rows == 512
+    else:
+        assert Pk.tile_rows in (512, 128, 64)
     try:
         ops.set_packed_enabled(True)
         for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (-0.5, 2.0)):

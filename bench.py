@@ -228,7 +228,8 @@ def main():
                 else "csr_sweep_kernel<JACOBI>",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": PMC_TRAFFIC.get((args.size, pk is not None)),
+                "traffic": PMC_TRAFFIC.get((args.size, pk is not None)) if (world == 1 and not force_dist
+                                                                            and args.problem == "poisson") else None,
                 "algorithmic_bytes_per_launch": B, "avg_launch_ms": t_jac * 1e3,
                 "rows_per_launch": int(fine_A.shape[0]),
                 "stored_bytes_per_launch": B_stored,

@@ -170,8 +170,13 @@ class DistributedVCycle:
                 want = gathered[q][l]
                 mine = want[(want >= lo) & (want < hi)] - lo + d.n_lo
                 if mine.size:
-                    d.send.append((q, torch.from_numpy(mine.astype(np.int32)).to(self.device),
-                                   torch.empty(mine.size, dtype=F64, device=self.device)))
+                    if mine.size == int(mine[-1]) - int(mine[0]) + 1:
+                        # structured row blocks: the boundary grid line is one contiguous run,
+                        # sent straight out of the vector (no pack kernel, no staging buffer)
+                        d.send.append((q, (int(mine[0]), int(mine[-1]) + 1), None))
+                    else:
+                        d.send.append((q, torch.from_numpy(mine.astype(np.int32)).to(self.device),
+                                       torch.empty(mine.size, dtype=F64, device=self.device)))
             for name in ("x", "b", "r", "tmp"):
                 setattr(d, name, torch.zeros(d.n_tot, dtype=F64, device=self.device))
             self.dl.append(d)
@@ -209,6 +214,8 @@ class DistributedVCycle:
         idx = np.concatenate([np.arange(cb[p + 1] - cb[p]) + p * self.ag_max for p in range(self.world)])
         self.ag_index = torch.from_numpy(idx.astype(np.int32)).to(self.device)
         self.ag_rows = cb[self.rank + 1] - cb[self.rank]
+        self.use_tail_graph = True
+        self._tail_graphs = {}
         self.partials = torch.empty(max(1024, self.ops.partials_count(self.dl[0].n_tot)), dtype=F64,
                                     device=self.device)
         self.norm2 = torch.zeros(1, dtype=F64, device=self.device)
@@ -241,7 +248,10 @@ class DistributedVCycle:
             return
         p2p = []
         for q, idx, buf in d.send:
-            self.ops.gather(idx, vec, buf)
+            if isinstance(idx, tuple):                      # contiguous run of owned rows: no pack kernel
+                buf = vec[idx[0]:idx[1]]
+            else:
+                self.ops.gather(idx, vec, buf)
             p2p.append(dist.P2POp(dist.isend, buf, q, group=self.group))
         for q, off, cnt in d.recv:
             p2p.append(dist.P2POp(dist.irecv, vec[off:off + cnt], q, group=self.group))
@@ -302,12 +312,35 @@ class DistributedVCycle:
             o.csr_spmv(d.R, d.r, self.ag_send[:self.ag_rows], 1.0, 0.0)
             dist.all_gather_into_tensor(self.ag_recv, self.ag_send, group=self.group)
             o.gather(self.ag_index, self.ag_recv, fl.b)
-            if l + 2 == len(self.full.levels):
-                self.full.coarse_solve()
-            else:
-                self.full.cycle(smoother, steps, omega, l=l + 1, x_is_zero=True)
+            self._replicated_tail(smoother, steps, omega, l + 1)
             o.csr_spmv(d.P, fl.x, d.x, 1.0, 1.0)
         self._smooth(d, steps, omega)
+
+    def _replicated_tail(self, smoother, steps, omega, l):
+        """The part of the cycle below the distributed levels: purely local work on the
+        replicated hierarchy, so it is captured once into a hipGraph and replayed (the RCCL
+        calls above it stay eager)."""
+        def run():
+            if l + 1 == len(self.full.levels):
+                self.full.coarse_solve()
+            else:
+                self.full.cycle(smoother, steps, omega, l=l, x_is_zero=True)
+
+        if not self.use_tail_graph or not hasattr(self.ops, "CapturedGraph") or self.device.type != "cuda":
+            run()
+            return
+        key = (smoother, steps, omega, l)
+        g = self._tail_graphs.get(key)
+        if g is None:
+            before = [(lev.x, lev.tmp) for lev in self.full.levels]
+            g = self.ops.CapturedGraph()
+            with g:
+                run()
+            after = [(lev.x, lev.tmp) for lev in self.full.levels]
+            if any(a[0] is not b[0] for a, b in zip(before, after)):
+                raise RuntimeError("ping-pong buffers did not return to their slots")
+            self._tail_graphs[key] = g
+        g.launch()
 
     def residual_norm(self):
         """||b - A x||_2 over all ranks: local fused sum of squares + all-reduce of 8 bytes."""

@@ -83,8 +83,11 @@ __device__ __forceinline__ void stage_bytes(const unsigned char *g, long lo16, l
 
 // JU = entries of each row handled per step (JU x 4 independent gathers in flight per thread)
 // EXP (timing experiments only, wrong results): 1 = no x gathers, 2 = no gathers and no staging
+#ifndef LMG_PCSR_WAVES
+#define LMG_PCSR_WAVES 1
+#endif
 template <int MODE, int COLMODE, int VALMODE, int JU, int EXP = 0, int kBlock = 128, int kRpt = 4>
-__global__ void __launch_bounds__(kBlock) pcsr_sweep_kernel(PArgs a)
+__global__ void __launch_bounds__(kBlock, LMG_PCSR_WAVES) pcsr_sweep_kernel(PArgs a)
 {
     constexpr int kTileRows = kBlock * kRpt;
     constexpr int NW = kBlock / LMG_WAVE;

@@ -137,9 +137,9 @@ class Hierarchy:
             lev = self.levels[l]
             lev.plan_RA.numeric(lev.R, lev.A, out=lev.RA)
             lev.plan_RAP.numeric(lev.RA, lev.P, out=self.levels[l + 1].A)
-        for lev in self.levels:
-            lev.A.invalidate_packed()
-        self._pack_all()
+        if self.use_packed:
+            for lev in self.levels:
+                lev.A.repack_values()            # same pattern: only the value streams change
         self._inverse_diagonals()
         self._factor_coarsest()
         self._graphs = {}

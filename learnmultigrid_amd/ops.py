@@ -58,6 +58,12 @@ class DeviceCSR:
     def invalidate_packed(self):
         self.packed = None
 
+    def repack_values(self):
+        """After the values changed in place: refresh the packed twin (cheaply if possible)."""
+        if self.packed is not None and not self.packed.update_values(self):
+            self.packed = None
+            self.pack()
+
     @classmethod
     def from_scipy(cls, A, device, canonical=True):
         """Any scipy.sparse matrix / ndarray -> sorted, duplicate-free CSR on `device`
@@ -172,6 +178,29 @@ class PackedCSR:
 
     def bytes(self):
         return int(self.bytes_)
+
+    def update_values(self, A):
+        """New values, same sparsity pattern (Galerkin rebuild): only the value stream (and the
+        dictionary) is re-encoded; returns False when the value encoding no longer fits and the
+        caller has to repack from scratch."""
+        if A.nnz != self.nnz:
+            return False
+        if self.valmode == 2:
+            self.val[: self.nnz * 8].view(F64).copy_(A.vals)
+            return True
+        bits = A.vals.view(torch.int64)
+        uniq = torch.unique(bits)
+        nd = int(uniq.numel())
+        if (self.valmode == 0 and nd > 256) or (self.valmode == 1 and nd > 65536):
+            return False
+        idx = torch.searchsorted(uniq, bits)
+        if self.valmode == 0:
+            self.val[: self.nnz].copy_(idx.to(torch.uint8))
+        else:
+            self.val[: self.nnz * 2].view(torch.int16).copy_(idx.to(torch.int16))
+        self.dict = uniq.view(F64).contiguous()
+        self.ndict = nd
+        return True
 
 
 _PACKED_ENABLED = True

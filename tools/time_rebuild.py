@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Break down Hierarchy.rebuild_numeric (config #5's Galerkin rebuild) into its phases."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import scipy.sparse as sp
+from learnmultigrid_amd import problems as P
+from learnmultigrid_amd.hierarchy import Hierarchy
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=4096)
+ap.add_argument("--levels", type=int, default=6)
+ap.add_argument("--transfer", default="learned")
+a = ap.parse_args()
+m = a.size
+A, rhs = P.variable_coeff_poisson_2d_structured(m, seed=44)
+A2, _ = P.variable_coeff_poisson_2d_structured(m, seed=45)
+hier = []
+for li, sz in enumerate(P.level_sizes(m + 1, a.levels)[:-1]):
+    if a.transfer == "learned":
+        l2 = P.pseudo_l2_interpolator_1d(sz)
+        hier.append(P.learned_like(sp.kron(l2, l2).tocsr(), 43 + li))
+    else:
+        hier.append(P.tensor_interpolator_2d(sz))
+t0 = time.perf_counter(); H = Hierarchy(A, hier, "cuda:0"); torch.cuda.synchronize(); print("setup %.3f s" % (time.perf_counter() - t0))
+newv = torch.from_numpy(A2.data.copy()).to("cuda:0")
+def T(f, name):
+    torch.cuda.synchronize(); t = time.perf_counter(); f(); torch.cuda.synchronize(); print("%-28s %8.2f ms" % (name, (time.perf_counter() - t) * 1e3))
+def numeric():
+    H.levels[0].A.vals.copy_(newv)
+    for l in range(len(H.levels) - 1):
+        lev = H.levels[l]
+        lev.plan_RA.numeric(lev.R, lev.A, out=lev.RA)
+        lev.plan_RAP.numeric(lev.RA, lev.P, out=H.levels[l + 1].A)
+for _ in range(2):
+    T(numeric, "numeric SpGEMM (all levels)")
+    T(lambda: [lev.A.repack_values() for lev in H.levels], "repack values")
+    T(H._inverse_diagonals, "inverse diagonals")
+    T(H._factor_coarsest, "coarse factorisation")
+    T(lambda: H.rebuild_numeric(newv), "rebuild_numeric total")
+print("levels", H.sizes, "coarse", H.coarse.kind)

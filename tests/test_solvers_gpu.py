@@ -348,3 +348,45 @@ def test_cfg5_style_variable_coefficient_rebuild_and_solve():
     want = ref.track_res.ravel()
     got = np.array(norms)
     np.testing.assert_allclose(got[1:], want[1:], rtol=1e-10)           # (entry 0 is the sqrt(n) quirk)
+
+
+@pytest.mark.parametrize("ne,levels,steps", [(15, 2, 1), (15, 3, 2), (16, 4, 1), (33, 3, 0), (64, 6, 1)])
+def test_edge_cases_match_oracle(ne, levels, steps):
+    """Even n (the interpolator quirk of Multigrid.py:139-142), coarsest grids of 2-3 unknowns,
+    zero smoothing steps: same histories as the CPU oracle."""
+    A, rhs = P.poisson_1d_fd(ne)
+    for sem, name, om in (("as_shipped", "GaussSeidel", 1.0), ("as_named", "Jacobi", 0.7)):
+        ref = V.RefMultigrid(A, rhs.copy())
+        ref.solve(levels=levels, smoother=name, smooth_steps=steps, max_iterations=12, error=1e-12,
+                  semantics=sem, omega=om)
+        mg = GeometricMG(A, rhs.copy())
+        mg.solve(levels=levels, smoother=name, smooth_steps=steps, max_iterations=12, error=1e-12,
+                 smoother_semantics=sem, omega=om)
+        assert mg.get_iterations() == ref.iterations
+        assert mg.level_dims == ref.level_dims
+        assert_track(mg.get_track_res(), ref.track_res, floor=1e-13)
+
+
+def test_degenerate_calls():
+    A, rhs = P.poisson_1d_fd(32)
+    mg = GeometricMG(A, rhs.copy())
+    mg.solve(levels=2, max_iterations=1)                      # one started iteration, no convergence
+    assert mg.get_iterations() == 1 and mg.get_track_res().shape == (1, 1)
+    assert mg.get_track_res()[0, 0] == np.sqrt(33) and np.array_equal(mg.get_residual_vector(), np.ones((33, 1)))
+    mg = GeometricMG(A, rhs.copy())
+    mg.solve(levels=2, error=100.0)                           # sqrt(33) <= 100: stops before any cycle
+    assert mg.get_iterations() == 1 and not mg.get_solution().any()
+    mg = GeometricMG(A, np.zeros((33, 1)))
+    mg.solve(levels=3, max_iterations=5, error=1e-12)         # zero rhs: exact after the first check
+    assert mg.get_iterations() == 2 and mg.get_track_res()[1, 0] == 0.0
+    x0 = np.linspace(0, 1, 33).reshape(-1, 1)
+    ref = V.RefMultigrid(A, rhs.copy())
+    ref.solve(levels=3, smoother="Jacobi", smooth_steps=2, max_iterations=6, error=1e-30,
+              initial_guess=x0.copy(), semantics="as_named", omega=0.8)
+    mg = GeometricMG(A, rhs.copy())
+    mg.solve(levels=3, smoother="Jacobi", smooth_steps=2, max_iterations=6, error=1e-30,
+             initial_guess=x0.copy(), smoother_semantics="as_named", omega=0.8)
+    assert_track(mg.get_track_res(), ref.track_res)
+    # solving twice with the same object keeps counting iterations like the reference (no reset)
+    mg.solve(levels=3, max_iterations=2, error=1e-30)
+    assert mg.get_iterations() == 8

@@ -92,6 +92,9 @@ class DistributedVCycle:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.stream = getattr(full, "stream", None)
+        # "gloo" cannot move device tensors point to point: when it drives GPU ranks (tests that put
+        # several ranks on one GPU, or a node without RCCL) messages are staged through the host
+        self.host_staged = self.device.type == "cuda" and dist.get_backend(group) == "gloo"
         nlev = len(full.levels)
         sizes = [lev.n for lev in full.levels]
         # ---- which levels are distributed -------------------------------------------------
@@ -246,17 +249,26 @@ class DistributedVCycle:
         """Fill the ghost segment of `vec` (layout of level d) from the owning ranks."""
         if not d.recv and not d.send:
             return
-        p2p = []
+        p2p, landing = [], []
         for q, idx, buf in d.send:
             if isinstance(idx, tuple):                      # contiguous run of owned rows: no pack kernel
                 buf = vec[idx[0]:idx[1]]
             else:
                 self.ops.gather(idx, vec, buf)
+            if self.host_staged:
+                buf = buf.cpu()
             p2p.append(dist.P2POp(dist.isend, buf, q, group=self.group))
         for q, off, cnt in d.recv:
-            p2p.append(dist.P2POp(dist.irecv, vec[off:off + cnt], q, group=self.group))
+            dst = vec[off:off + cnt]
+            if self.host_staged:
+                host = torch.empty(cnt, dtype=F64)
+                landing.append((dst, host))
+                dst = host
+            p2p.append(dist.P2POp(dist.irecv, dst, q, group=self.group))
         for req in dist.batch_isend_irecv(p2p):
             req.wait()
+        for dst, host in landing:
+            dst.copy_(host)
 
     def set_rhs(self, rhs):
         d = self.dl[0]
@@ -310,7 +322,12 @@ class DistributedVCycle:
         else:
             fl = self.full.levels[l + 1]
             o.csr_spmv(d.R, d.r, self.ag_send[:self.ag_rows], 1.0, 0.0)
-            dist.all_gather_into_tensor(self.ag_recv, self.ag_send, group=self.group)
+            if self.host_staged:
+                recv = torch.empty(self.ag_recv.numel(), dtype=F64)
+                dist.all_gather_into_tensor(recv, self.ag_send.cpu(), group=self.group)
+                self.ag_recv.copy_(recv)
+            else:
+                dist.all_gather_into_tensor(self.ag_recv, self.ag_send, group=self.group)
             o.gather(self.ag_index, self.ag_recv, fl.b)
             self._replicated_tail(smoother, steps, omega, l + 1)
             o.csr_spmv(d.P, fl.x, d.x, 1.0, 1.0)
@@ -347,6 +364,10 @@ class DistributedVCycle:
         d = self.dl[0]
         self.exchange(d, d.x)
         self.ops.csr_residual_norm2(d.A, d.x, d.b, d.r, self.partials, self.norm2)
+        if self.host_staged:
+            h = self.norm2.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            return math.sqrt(h.item())
         dist.all_reduce(self.norm2, op=dist.ReduceOp.SUM, group=self.group)
         return math.sqrt(self.norm2.item())
 

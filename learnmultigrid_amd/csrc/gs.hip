@@ -61,6 +61,78 @@ __global__ void __launch_bounds__(kSingleBlock) gs_single_wg_kernel(
     }
 }
 
+// Chain-like schedules (sets of one or two rows: 1-D problems, where the level schedule
+// degenerates to the sequential sweep).  One wave; the row data of 64 consecutive rows is fetched by the
+// 64 lanes at once (it does not depend on x), then the 64 rows are relaxed one after the
+// other, lane l at step l, with x held in LDS when it fits (the only serial dependence is the
+// x[i-1] -> x[i] hand-over: one LDS round trip instead of a workgroup barrier plus a global
+// round trip per row).  Same row arithmetic and order as gs_update_row.
+constexpr int kChainK = 8;     // entries of a row kept in registers; longer rows read the rest from memory
+template <bool X_IN_LDS>
+__global__ void __launch_bounds__(64) gs_chain_kernel(const int *rowptr, const int *colidx,
+                                                      const double *vals, double *x, const double *b,
+                                                      const int *rows, int nrows, int n, int sweeps)
+{
+    extern __shared__ double s_x[];
+    const int lane = threadIdx.x;
+    if (X_IN_LDS) {
+        for (int i = lane; i < n; i += 64) s_x[i] = x[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    for (int sw = 0; sw < sweeps; ++sw) {
+        for (int c0 = 0; c0 < nrows; c0 += 64) {
+            const int k = c0 + lane;
+            const bool valid = k < nrows;
+            const int row = valid ? rows[k] : 0;
+            const int rs = valid ? rowptr[row] : 0;
+            const int len = valid ? rowptr[row + 1] - rs : 0;
+            const double bi = valid ? b[row] : 0.0;
+            int cj[kChainK];
+            double vj[kChainK];
+#pragma unroll
+            for (int q = 0; q < kChainK; ++q) {
+                cj[q] = (q < len) ? colidx[rs + q] : -1;
+                vj[q] = (q < len) ? vals[rs + q] : 0.0;
+            }
+            const int steps = min(64, nrows - c0);
+            for (int l = 0; l < steps; ++l) {
+                if (lane == l) {
+                    double rsum = 0.0, diag = 0.0;
+#pragma unroll
+                    for (int q = 0; q < kChainK; ++q) {
+                        if (q < len) {
+                            const int j = cj[q];
+                            if (j == row) diag = vj[q];
+                            else rsum += vj[q] * (X_IN_LDS ? s_x[j] : x[j]);
+                        }
+                    }
+                    for (int q = kChainK; q < len; ++q) {
+                        const int j = colidx[rs + q];
+                        const double v = vals[rs + q];
+                        if (j == row) diag = v;
+                        else rsum += v * (X_IN_LDS ? s_x[j] : x[j]);
+                    }
+                    if (diag != 0.0) {
+                        const double xn = (bi - rsum) / diag;
+                        if (X_IN_LDS) s_x[row] = xn;
+                        else x[row] = xn;
+                    }
+                }
+                // hand-over to the next lane: same wave, but the compiler must not move the
+                // next lane's reads above this lane's write
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+        }
+    }
+    if (X_IN_LDS) {
+        for (int i = lane; i < n; i += 64) x[i] = s_x[i];
+    }
+}
+
 // Pattern of A^T (CSC of A) on the host: counting sort by column.
 void transpose_pattern(int64_t n, const int32_t *Ap, const int32_t *Aj, std::vector<int32_t> &Tp,
                        std::vector<int32_t> &Tj)
@@ -105,6 +177,28 @@ int lmg_csr_gs_schedule(const int32_t *rp, const int32_t *ci, const double *va, 
     if (nsets == 0 || sweeps == 0) return LMG_OK;
     if (!d_set_rows || !d_set_ptr || !h_set_ptr) return LMG_ERR_ARG;
     hipStream_t st = lmg_stream(stream);
+    const int64_t total_rows = h_set_ptr[nsets];
+    if (total_rows <= 4 * nsets && total_rows < (1 << 30)) {
+        // (nearly) a chain: relaxing the rows one after the other in schedule order is the
+        // same sweep (rows of one set are independent) and avoids a barrier per set
+        const int n = (int)total_rows;
+        const size_t lds = (size_t)n * sizeof(double);
+        if (lds <= 144 * 1024) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gs_chain_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(gs_chain_kernel<true>, dim3(1), dim3(64), lds, st, rp, ci, va, x, b, d_set_rows, n,
+                               n, sweeps);
+        } else {
+            hipLaunchKernelGGL(gs_chain_kernel<false>, dim3(1), dim3(64), 0, st, rp, ci, va, x, b, d_set_rows, n,
+                               n, sweeps);
+        }
+        LMG_CHECK_LAUNCH();
+        return LMG_OK;
+    }
     if (max_set <= 2 * kSingleBlock) {
         hipLaunchKernelGGL(gs_single_wg_kernel, dim3(1), dim3(kSingleBlock), 0, st, rp, ci, va, x, b,
                            d_set_rows, d_set_ptr, nsets, sweeps);

@@ -240,3 +240,34 @@ class HierarchyMG(SemiGeometricMG):
         hierarchy = list(hierarchy)
         super().__init__(matrix, rhs, hierarchy[0], hierarchy=hierarchy, **kw)
         self.label = "HierarchyMG"
+
+
+class NeuralMG(Multigrid):
+    """Multigrid.py:200-370: `NeuralMG(matrix, rhs, model, M, std, mean)`.  The transfer operator of
+    every level is built from that level's mass matrix by the caller's model
+    (`model.predict`, any object; see learned_q.py for the scatter) and the mass matrix is
+    coarsened with it, M_c = Q^T M Q (:273-275).  The reference asks the model again in every
+    cycle; a deterministic model returns the same Q each time, so the operators are built once
+    per solve() here (setup / solve split) and the cycles run on the device."""
+
+    def __init__(self, matrix, rhs, model, M, std, mean, **kw):
+        super().__init__(matrix, rhs, **kw)
+        self._log("Selected NN Multigrid")
+        self.label = "NeuralMG"
+        self.model, self.M, self.std, self.mean = model, M, std, mean
+
+    def transfer_op(self, M):
+        from ..learned_q import learned_transfer
+        return learned_transfer(self.model, M, self.mean, self.std)                 # :306-311
+
+    def _transfers(self, levels, first_call):
+        out = []
+        M = np.asarray(self.M.todense()) if hasattr(self.M, "todense") else np.asarray(self.M)
+        for _ in range(levels - 1):
+            if M.shape[0] % 2 == 0:
+                raise ValueError("mass matrix of even size %d: the learned 1-D transfer needs odd sizes "
+                                 "(test/test_B_patch.py:52-53)" % M.shape[0])
+            Q = self.transfer_op(M)
+            out.append(sp.csr_matrix(Q))
+            M = np.asarray(sp.csr_matrix(Q.T @ M @ Q).toarray())                    # :273-275
+        return out

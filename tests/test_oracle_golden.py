@@ -164,3 +164,36 @@ def test_hoisted_cycle_matches_faithful_cycle():
     h = V.HoistedVCycle(A, hier)
     uh = h.cycle(np.zeros(65), rhs, "GaussSeidel", 2)
     np.testing.assert_allclose(uh, u.ravel(), rtol=1e-11, atol=1e-15)
+
+
+class ReplayModel:
+    """Feeds back the predictions recorded from the reference run (fixture g7), keyed by the
+    number of patches, and checks that it is shown the same features."""
+
+    def __init__(self, g):
+        self.table = {g["features_l0"].shape[0]: (g["features_l0"], g["pred_l0"]),
+                      g["features_l1"].shape[0]: (g["features_l1"], g["pred_l1"])}
+        self.calls = 0
+
+    def predict(self, data):
+        feats, pred = self.table[data.shape[0]]
+        np.testing.assert_allclose(data, feats, rtol=1e-11, atol=1e-16)
+        self.calls += 1
+        return pred
+
+
+def test_g7_neuralmg_multilevel():
+    from conftest import load_golden, coo_from
+    g = load_golden("g7_neuralmg_ne64")
+    A, rhs, M = coo_from(g, "A"), g["rhs"], g["M"]
+    model = ReplayModel(g)
+    m = V.RefNeuralMG(A, rhs, model, M, np.ones(7), np.zeros(7))
+    m.solve(levels=3, smoother="GaussSeidel", smooth_steps=3, error=1e-10, max_iterations=12)
+    assert m.iterations == int(g["iterations"])
+    assert_track(m.track_res, g["track"], 1e-9)
+    assert model.calls == int(g["n_predict_calls"])          # asked again in every cycle, like the reference
+    # the product's vectorised scatter is bit-identical to the reference's
+    from learnmultigrid_amd import learned_q as LQ
+    assert np.array_equal(LQ.patch_features(M), g["features_l0"])
+    g3 = load_golden("g3_fem1d_ne32")
+    assert np.array_equal(LQ.transfer_from_predictions(g3["fake_pred"], g3["M"]), coo_from(g3, "Q_learned").toarray())

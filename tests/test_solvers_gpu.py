@@ -390,3 +390,17 @@ def test_degenerate_calls():
     # solving twice with the same object keeps counting iterations like the reference (no reset)
     mg.solve(levels=3, max_iterations=2, error=1e-30)
     assert mg.get_iterations() == 8
+
+
+def test_g7_neuralmg_constructor_and_multilevel_run():
+    from learnmultigrid_amd.solvers import NeuralMG
+    from test_oracle_golden import ReplayModel
+    g = load_golden("g7_neuralmg_ne64")
+    A, rhs, M = coo_from(g, "A"), g["rhs"], g["M"]
+    mg = NeuralMG(A, rhs, ReplayModel(g), M, np.ones(7), np.zeros(7))
+    mg.solve(levels=3, smoother="GaussSeidel", smooth_steps=3, error=1e-10, max_iterations=12)
+    assert mg.get_iterations() == int(g["iterations"])
+    assert_track(mg.get_track_res(), g["track"])
+    assert mg.level_dims == [65, 33, 17] and mg.label == "NeuralMG"
+    with pytest.raises(ValueError):
+        NeuralMG(A[:64, :64], rhs[:64], ReplayModel(g), M[:64, :64], np.ones(7), np.zeros(7)).solve(levels=2)

@@ -325,6 +325,54 @@ def g5_saved_files():
     print("wrote g5_saved_A.npz / g5_saved_rhs.npy with the reference's save()")
 
 
+class ScaleAwareFakeModel:
+    """Like FakeModel, but scales its stencil with the mass-matrix entries it is shown, so that it
+    behaves sensibly on every level of a multi-level NeuralMG run (std = 1, mean = 0)."""
+
+    def __init__(self, seed):
+        self.seed = seed
+        self.calls = []
+
+    def predict(self, data):
+        rng = np.random.RandomState(self.seed + data.shape[0])
+        base = np.array([0, 0, 1 / 12, 0, 1 / 2, 5 / 6, 1 / 2, 0, 1 / 12])
+        out = base[None, :] * (1.5 * data[:, 1:2]) * (1.0 + 0.05 * rng.standard_normal((data.shape[0], 9)))
+        self.calls.append((data.copy(), out.copy()))
+        return out
+
+
+def g7_neural_mg_multilevel():
+    """NeuralMG(...).solve(levels=3) (Multigrid.py:200-370, call shape of
+    test/test_more_levels_NN.py:62-63) with a deterministic stand-in model: Q is rebuilt from
+    the coarsened mass matrix on every level."""
+    def fm1(x):
+        return -1
+    ne = 64
+    np.random.seed(4321)
+    mesh = Mesh1D(regular=False, ne=ne)
+    quiet(mesh.construct)
+    q, phi, dphi = Quadrature(3), Function(2), Gradient(2)
+    A = quiet(StiffnessMatrix(mesh).compute_stiffness_1d, dphi, q)
+    M = quiet(MassMatrix(mesh).compute_mass_1d, phi, q)
+    rhs = quiet(LoadVector(mesh).compute_rhs_1d, fm1)
+    rhs[0] = 0
+    rhs[-1] = 0
+    A[1, 0] = 0
+    A[-2, -1] = 0
+    A[0, :] = 0
+    A[-1, :] = 0
+    A[0, 0] = 1
+    A[-1, -1] = 1
+    model = ScaleAwareFakeModel(seed=99)
+    nmg = quiet(NeuralMG, A, rhs, model, M, np.ones(7), np.zeros(7))
+    quiet(nmg.solve, levels=3, smoother="GaussSeidel", smooth_steps=3, error=1e-10, max_iterations=12)
+    # the first two predict() calls belong to the first cycle: level 0 and level 1
+    (d0, p0), (d1, p1) = model.calls[0], model.calls[1]
+    save("g7_neuralmg_ne64", rhs=rhs, M=np.asarray(M), **coo(sp.csr_matrix(A), "A"),
+         track=nmg.get_track_res(), iterations=nmg.get_iterations(), solution=nmg.get_solution(),
+         features_l0=d0, pred_l0=p0, features_l1=d1, pred_l1=p1, n_predict_calls=len(model.calls))
+
+
 def g6_cg():
     """CG.py needs np.asscalar (removed in NumPy 1.23): shimmed for this run only."""
     from learn_multigrid.solvers.CG import CG
@@ -341,6 +389,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     g5_saved_files()
     g6_cg()
+    g7_neural_mg_multilevel()
     rel = g2_gs_crosscheck()
     g1_small_solvers()
     g2_interpolators()

@@ -112,13 +112,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test knobs: LMG_FORCE_DEVICE puts every rank on one GPU and LMG_DIST_BACKEND=gloo moves the
+    # messages through the host (RCCL refuses two ranks per device) -- rehearsal of the N > 1 path
+    # on a one-GPU box; the driver's runs use neither
+    if os.environ.get("LMG_FORCE_DEVICE"):
+        local = int(os.environ["LMG_FORCE_DEVICE"])
+    backend = os.environ.get("LMG_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     force_dist = os.environ.get("LMG_FORCE_DIST") == "1"     # drive the partitioned path on 1 GPU
     if world > 1 or force_dist:
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.variant >= 0:
         ops.tune_set("sweep_variant", args.variant)
     if args.no_packed:
@@ -195,7 +204,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
         sweeps_per_step = 2 if args.mode == "sweep" else 2 * nu + 1

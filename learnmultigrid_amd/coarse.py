@@ -28,7 +28,7 @@ import numpy as np
 import scipy.sparse as sp
 import torch
 
-from .ops import DeviceCSR, F64, I32
+from .ops import DeviceCSR, F64
 
 MAX_DENSE = 46000          # 46000^2 * 8 B = 17 GB of the 288 GB HBM
 _INV_LEAF = 512

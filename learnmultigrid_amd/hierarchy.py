@@ -21,7 +21,7 @@ import scipy.sparse as sp
 import torch
 
 from . import ops
-from .coarse import MAX_DENSE as MAX_DENSE_COARSE, csr_to_dense, dense_inverse, make_coarse_solver  # noqa: F401
+from .coarse import make_coarse_solver
 from .ops import DeviceCSR, F64
 
 

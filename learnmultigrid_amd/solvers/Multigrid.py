@@ -29,7 +29,6 @@ import torch
 
 from .. import ops, problems
 from ..hierarchy import Hierarchy
-from ..ops import F64
 from .Solver import IterativeSolver
 
 _SMOOTHERS = ("GaussSeidel", "Jacobi", "CG")          # Multigrid.py:149-155

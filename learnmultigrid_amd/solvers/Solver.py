@@ -94,7 +94,7 @@ class DirectSolver(Solver):
     refinement by the HIP kernels -- meant for the small systems the scripts use it on."""
 
     def solve(self):
-        from ..hierarchy import MAX_DENSE_COARSE, csr_to_dense, dense_inverse
+        from ..coarse import MAX_DENSE as MAX_DENSE_COARSE, csr_to_dense, dense_inverse
         if self.dim > MAX_DENSE_COARSE:
             raise ValueError("DirectSolver on the device is limited to %d unknowns" % MAX_DENSE_COARSE)
         A = self._device_matrix()

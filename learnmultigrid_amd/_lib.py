@@ -8,6 +8,11 @@ import ctypes
 import os
 import subprocess
 
+# torch FIRST: PyTorch-ROCm ships its own libamdhip64; if liblmg_hip.so were loaded before it,
+# the dynamic linker would bind our kernels to /opt/rocm's copy and the process would end up
+# with two HIP runtimes (launches on torch's streams then fail with a HIP runtime error).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LMG_LIB_PATH selects another build of the same ABI (A/B runs of two kernel versions)
 LIB_PATH = os.environ.get("LMG_LIB_PATH") or os.path.join(_HERE, "liblmg_hip.so")

@@ -190,6 +190,20 @@ int64_t lmg_scan_scratch_count(int64_t n);
 int lmg_exclusive_scan_i32(int64_t n, const int32_t *d_in, int32_t *d_out, int32_t *d_scratch,
                            void *stream);
 
+/* ---- P1 assembly on triangles (the step before the hot path) ----------------------------------
+ * Stiffness (optionally element coefficient d_coeff[e]), mass and load vector (constant load
+ * f_const) of linear triangles, node-centric and atomic-free; replaces the element loops of
+ * assembly/StiffnessMatrix.py:21-36, MassMatrix.py:21-35, LoadVector.py:20-34.
+ *   d_px/d_py[n_nodes], d_conn[3*n_elem] (0-based);  node->element adjacency in element order:
+ *   d_n2e_ptr[n_nodes+1], d_n2e_elem[], d_n2e_loc[] (local vertex 0..2 of the node in that element);
+ *   d_rowptr/d_colidx: the CSR pattern of the mesh graph (node + neighbours), shared by A and M.
+ * Any of d_a_vals / d_m_vals / d_rhs may be NULL. */
+int lmg_p1_assemble_2d(int64_t n_nodes, const double *d_px, const double *d_py, const int32_t *d_conn,
+                       const int32_t *d_n2e_ptr, const int32_t *d_n2e_elem, const int32_t *d_n2e_loc,
+                       const double *d_coeff, double f_const, const int32_t *d_rowptr,
+                       const int32_t *d_colidx, double *d_a_vals, double *d_m_vals, double *d_rhs,
+                       void *stream);
+
 /* ---- hipGraph capture of a launch sequence (one V-cycle) -----------------------------
  * begin/end bracket launches issued on `stream`; end returns an opaque executable graph. */
 int lmg_graph_begin(void *stream);

@@ -100,6 +100,33 @@ int lmg_pcsr_sweep(int mode, int64_t n, int64_t nnz, int32_t tile_rows, int32_t 
                    const double *d_x, const double *d_b, double *d_out, double alpha, double beta,
                    double *d_partials, double *d_norm2, void *stream);
 
+/* ---- building the packed twin (setup) ----------------------------------------------
+ * One streaming pass each; learnmultigrid_amd/ops.py PackedCSR.from_csr is the calling sequence.
+ *   lmg_pcsr_tile_colrange   smallest / largest column of every tile of `tile_rows` rows
+ *                            (0 / 0 for an empty tile)
+ *   lmg_pcsr_encode_cols16   d_out[e] = uint16(d_colidx[e] - d_colbase[tile of e])
+ *   lmg_value_set_insert     inserts the bit patterns of d_vals into an open-addressing table
+ *                            (d_table: table_slots uint64, a power of two >= 2 * (limit + 262144),
+ *                            pre-filled with 0xFF bytes).  d_state[3] (zeroed by the caller):
+ *                            [0] distinct values seen, [1] != 0 if more than `limit` (the table
+ *                            content is then meaningless), [2] != 0 if the all-ones pattern --
+ *                            the empty marker -- occurs among the values.
+ *   lmg_value_encode         d_out[e] = index of d_vals[e] in d_dict (width 1: uint8, 2: uint16);
+ *                            d_dict sorted ascending as SIGNED 64-bit patterns; *d_missing is set
+ *                            when a value is not in the dictionary.
+ *   lmg_csr_inverse_diagonal d_dinv[i] = 1 / sum of the diagonal entries of row i, 0 when
+ *                            that sum is 0 or the row has no diagonal entry. */
+int lmg_pcsr_tile_colrange(int64_t n, int32_t tile_rows, const int32_t *d_rowptr, const int32_t *d_colidx,
+                           int32_t *d_cmin, int32_t *d_cmax, void *stream);
+int lmg_pcsr_encode_cols16(int64_t n, int32_t tile_rows, const int32_t *d_rowptr, const int32_t *d_colidx,
+                           const int32_t *d_colbase, uint16_t *d_out, void *stream);
+int lmg_value_set_insert(int64_t count, const double *d_vals, uint64_t *d_table, int64_t table_slots,
+                         int32_t limit, int32_t *d_state, void *stream);
+int lmg_value_encode(int64_t count, const double *d_vals, const double *d_dict, int32_t ndict, int width,
+                     void *d_out, int32_t *d_missing, void *stream);
+int lmg_csr_inverse_diagonal(int64_t n, const int32_t *d_rowptr, const int32_t *d_colidx, const double *d_vals,
+                             double *d_dinv, void *stream);
+
 /* ---- Gauss-Seidel ---------------------------------------------------------------
  * One independent set: for every i in d_rows, in place,
  *     x_i = (b_i - sum_{j != i} a_ij x_j) / a_ii      (skipped when a_ii == 0)

@@ -36,6 +36,11 @@ SIGNATURES = {
     "lmg_pcsr_tile_rows": (_c.c_int, []),
     "lmg_pcsr_sweep": (_c.c_int, [_c.c_int, _i64, _i64, _i32, _i32, _p, _p, _p, _p, _c.c_int, _p, _c.c_int, _p, _i32,
                                   _p, _p, _p, _f64, _f64, _p, _p, _p]),
+    "lmg_pcsr_tile_colrange": (_c.c_int, [_i64, _i32, _p, _p, _p, _p, _p]),
+    "lmg_pcsr_encode_cols16": (_c.c_int, [_i64, _i32, _p, _p, _p, _p, _p]),
+    "lmg_value_set_insert": (_c.c_int, [_i64, _p, _p, _i64, _i32, _p, _p]),
+    "lmg_value_encode": (_c.c_int, [_i64, _p, _p, _i32, _c.c_int, _p, _p, _p]),
+    "lmg_csr_inverse_diagonal": (_c.c_int, [_i64, _p, _p, _p, _p, _p]),
     "lmg_csr_gs_rows": (_c.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p]),
     "lmg_csr_gs_schedule": (_c.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _c.c_int, _p]),
     "lmg_host_gs_levels": (_i64, [_i64, _p, _p, _p]),

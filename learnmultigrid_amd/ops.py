@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check
+from ._lib import LmgError, check
 
 F64 = torch.float64
 I32 = torch.int32
@@ -109,24 +109,60 @@ class PackedCSR:
         out[: raw.numel()] = raw
         return out
 
+    _VSET_SLOTS = 1 << 20          # uint64 slots of the distinct-value table (8 MB)
+    _VSET_LIMIT = 65536            # more distinct values than this: raw fp64 stream
+
+    @staticmethod
+    def _padded_empty(nbytes, device):
+        return torch.zeros(((nbytes + 15) // 16) * 16 + 16, dtype=torch.uint8, device=device)
+
+    @classmethod
+    def _distinct_values(cls, vals):
+        """Sorted (as signed 64-bit patterns) distinct values of `vals`, or None when there are
+        more than _VSET_LIMIT of them.  Hash-set kernel + a sort of the few survivors instead of
+        sorting all nnz values."""
+        L = _lib.lib()
+        dev = vals.device
+        table = torch.full((cls._VSET_SLOTS,), -1, dtype=torch.int64, device=dev)
+        state = torch.zeros(4, dtype=I32, device=dev)
+        check(L.lmg_value_set_insert(vals.numel(), _p(vals), _p(table), cls._VSET_SLOTS, cls._VSET_LIMIT,
+                                     _p(state), _s()), "lmg_value_set_insert")
+        st = state.cpu()
+        if int(st[1]):
+            return None
+        keys = table[table != -1]
+        if int(st[2]):
+            keys = torch.cat([keys, torch.full((1,), -1, dtype=torch.int64, device=dev)])
+        if keys.numel() > cls._VSET_LIMIT:
+            return None
+        return torch.sort(keys).values.contiguous()
+
+    @staticmethod
+    def _encode_values(vals, uniq, width, out):
+        missing = torch.zeros(1, dtype=I32, device=vals.device)
+        check(_lib.lib().lmg_value_encode(vals.numel(), _p(vals), _p(uniq), int(uniq.numel()), width, _p(out),
+                                          _p(missing), _s()), "lmg_value_encode")
+        if int(missing):
+            raise LmgError("value dictionary does not cover the matrix values")
+
     @classmethod
     def from_csr(cls, A):
         n, nnz = A.shape[0], A.nnz
         if n == 0 or nnz == 0:
             return None
+        L = _lib.lib()
         dev = A.vals.device
         rowlen = (A.rowptr[1:] - A.rowptr[:-1])
         if int(rowlen.max()) > 255 or int(rowlen.min()) < 0:
             return None
         # value encoding first: it decides how many bytes an entry occupies in LDS
-        bits = A.vals.view(torch.int64)
-        uniq = torch.unique(bits)
-        ndict = int(uniq.numel())
+        uniq = cls._distinct_values(A.vals)
+        ndict = int(uniq.numel()) if uniq is not None else 1 << 30
         # tile height: 512 rows unless the rows are so long that a tile would not leave room for
         # several workgroups per CU (budget ~20 KB of LDS per tile); long-row tiles only exist
         # for the VAL8 / VAL64 encodings
         avg = nnz / n
-        T = int(_lib.lib().lmg_pcsr_tile_rows())
+        T = int(L.lmg_pcsr_tile_rows())
         bpe = 2 + (1 if ndict <= 256 else (2 if ndict <= 65536 else 8))
         if T * avg * bpe > 20480:
             T = 128 if 128 * avg * (2 + (1 if ndict <= 256 else 8)) <= 20480 else 64
@@ -142,32 +178,30 @@ class PackedCSR:
         self.tile_cap = int(tile_nnz.max())
         self.tile_base = tile_base
         self.rowlen = rowlen.to(torch.uint8).contiguous()
-        tile_of_entry = torch.repeat_interleave(torch.arange(ntile, device=dev), tile_nnz.long())
-        big = torch.iinfo(torch.int32).max
-        cmin = torch.full((ntile,), big, dtype=I32, device=dev).scatter_reduce(
-            0, tile_of_entry, A.colidx, reduce="amin", include_self=True)
-        cmax = torch.zeros(ntile, dtype=I32, device=dev).scatter_reduce(
-            0, tile_of_entry, A.colidx, reduce="amax", include_self=True)
-        cmin = torch.where(tile_nnz > 0, cmin, torch.zeros_like(cmin))
+        cmin = torch.empty(ntile, dtype=I32, device=dev)
+        cmax = torch.empty(ntile, dtype=I32, device=dev)
+        check(L.lmg_pcsr_tile_colrange(n, T, _p(A.rowptr), _p(A.colidx), _p(cmin), _p(cmax), _s()),
+              "lmg_pcsr_tile_colrange")
+        self.tile_colbase = cmin
         if int((cmax - cmin).max()) < 65536:
             self.colmode = 0
-            self.tile_colbase = cmin.contiguous()
-            rel = (A.colidx - cmin[tile_of_entry])
-            self.col = cls._padded(rel.to(torch.int16))          # wraps: read back as uint16
+            self.col = cls._padded_empty(2 * nnz, dev)
+            check(L.lmg_pcsr_encode_cols16(n, T, _p(A.rowptr), _p(A.colidx), _p(cmin), _p(self.col), _s()),
+                  "lmg_pcsr_encode_cols16")
         else:
             self.colmode = 1
-            self.tile_colbase = cmin.contiguous()
             self.col = cls._padded(A.colidx)
-        del tile_of_entry
         self.ndict = ndict
         if self.ndict <= 256:
             self.valmode = 0
-            self.val = cls._padded(torch.searchsorted(uniq, bits).to(torch.uint8))
-            self.dict = uniq.view(F64).contiguous()
+            self.val = cls._padded_empty(nnz, dev)
+            cls._encode_values(A.vals, uniq, 1, self.val)
+            self.dict = uniq.view(F64)
         elif self.ndict <= 65536:
             self.valmode = 1
-            self.val = cls._padded(torch.searchsorted(uniq, bits).to(torch.int16))
-            self.dict = uniq.view(F64).contiguous()
+            self.val = cls._padded_empty(2 * nnz, dev)
+            cls._encode_values(A.vals, uniq, 2, self.val)
+            self.dict = uniq.view(F64)
         else:
             self.valmode = 2
             self.val = cls._padded(A.vals)
@@ -188,17 +222,12 @@ class PackedCSR:
         if self.valmode == 2:
             self.val[: self.nnz * 8].view(F64).copy_(A.vals)
             return True
-        bits = A.vals.view(torch.int64)
-        uniq = torch.unique(bits)
-        nd = int(uniq.numel())
+        uniq = self._distinct_values(A.vals)
+        nd = int(uniq.numel()) if uniq is not None else 1 << 30
         if (self.valmode == 0 and nd > 256) or (self.valmode == 1 and nd > 65536):
             return False
-        idx = torch.searchsorted(uniq, bits)
-        if self.valmode == 0:
-            self.val[: self.nnz].copy_(idx.to(torch.uint8))
-        else:
-            self.val[: self.nnz * 2].view(torch.int16).copy_(idx.to(torch.int16))
-        self.dict = uniq.view(F64).contiguous()
+        self._encode_values(A.vals, uniq, 1 if self.valmode == 0 else 2, self.val)
+        self.dict = uniq.view(F64)
         self.ndict = nd
         return True
 
@@ -336,14 +365,13 @@ def vmul(alpha, x, y, out):
 
 def csr_inverse_diagonal(A):
     """1/a_ii per row (0 where the diagonal is missing or zero); setup-time helper for the
-    zero-initial-guess Jacobi sweep.  Duplicate diagonal entries are summed like in the sweep."""
+    zero-initial-guess Jacobi sweep.  Duplicate diagonal entries are summed in storage order,
+    like in the sweep."""
     n = A.shape[0]
-    rows = torch.repeat_interleave(torch.arange(n, device=A.vals.device, dtype=torch.int64),
-                                   (A.rowptr[1:] - A.rowptr[:-1]).long())
-    on_diag = A.colidx.long() == rows
-    d = torch.zeros(n, dtype=F64, device=A.vals.device)
-    d.index_add_(0, rows[on_diag], A.vals[on_diag])
-    return torch.where(d != 0, 1.0 / d, torch.zeros_like(d))
+    d = torch.empty(n, dtype=F64, device=A.vals.device)
+    check(_lib.lib().lmg_csr_inverse_diagonal(n, _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(d), _s()),
+          "lmg_csr_inverse_diagonal")
+    return d
 
 
 def copy(src, dst):

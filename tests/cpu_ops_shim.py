@@ -67,7 +67,15 @@ def vmul(alpha, x, y, out):
     _np(out)[:] = alpha * (_np(x) * _np(y))
 
 
-from learnmultigrid_amd.ops import csr_inverse_diagonal  # noqa: E402,F401  (pure torch)
+def csr_inverse_diagonal(A):
+    n, rp, ci, va = _raw(A)
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    d = np.zeros(n)
+    on = ci == rows
+    np.add.at(d, rows[on], va[on])
+    out = np.zeros(n)
+    np.divide(1.0, d, out=out, where=d != 0)
+    return torch.from_numpy(out)
 
 
 def copy(src, dst):

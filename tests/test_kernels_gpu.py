@@ -480,3 +480,147 @@ def test_packing_is_refused_for_rows_longer_than_255_and_preserves_signed_zero()
     ref = np.empty(2)
     K.lib().orc_csr_matvec(2, M.indptr.astype(np.int32), M.indices.astype(np.int32), M.data, x, ref)
     assert np.array_equal(np.signbit(got), np.signbit(ref)) and np.array_equal(got, ref)
+
+
+def _numpy_pack(A, T):
+    """The packed format restated with numpy (what lmg.h documents), to check the device build."""
+    n = A.shape[0]
+    rp, ci, va = A.indptr, A.indices, A.data
+    ntile = (n + T - 1) // T
+    base = np.array([rp[min(t * T, n)] for t in range(ntile + 1)])
+    cmin = np.zeros(ntile, dtype=np.int64)
+    cmax = np.zeros(ntile, dtype=np.int64)
+    for t in range(ntile):
+        seg = ci[base[t]:base[t + 1]]
+        if seg.size:
+            cmin[t], cmax[t] = seg.min(), seg.max()
+    rel = ci - np.repeat(cmin, np.diff(base))
+    uniq = np.unique(va.view(np.int64))
+    return base, cmin, cmax, rel, uniq, np.searchsorted(uniq, va.view(np.int64))
+
+
+@pytest.mark.parametrize("name", ["val8_col16_poisson2d_513", "val16_col16_ragged", "val16_col32_random",
+                                  "val8_longrows_l2_galerkin", "galerkin_9pt", "val8_col16_restrict"])
+def test_packed_format_matches_its_numpy_restatement(name):
+    A = packed_case(name)
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    Pk = dA.pack()
+    base, cmin, cmax, rel, uniq, idx = _numpy_pack(A, Pk.tile_rows)
+    nnz = A.nnz
+    assert np.array_equal(Pk.tile_base.cpu().numpy(), base)
+    assert np.array_equal(Pk.tile_colbase.cpu().numpy(), cmin)
+    assert np.array_equal(Pk.rowlen.cpu().numpy(), np.diff(A.indptr))
+    assert Pk.tile_cap == np.diff(base).max()
+    if Pk.colmode == 0:
+        assert (cmax - cmin).max() < 65536
+        assert np.array_equal(Pk.col[:2 * nnz].view(torch.int16).cpu().numpy().view(np.uint16), rel)
+    else:
+        assert (cmax - cmin).max() >= 65536
+        assert np.array_equal(Pk.col[:4 * nnz].view(torch.int32).cpu().numpy(), A.indices)
+    if Pk.valmode == 2:
+        assert np.array_equal(Pk.val[:8 * nnz].view(torch.float64).cpu().numpy(), A.data)
+    else:
+        assert Pk.ndict == uniq.size
+        assert np.array_equal(Pk.dict.view(torch.int64).cpu().numpy(), uniq)
+        if Pk.valmode == 0:
+            assert np.array_equal(Pk.val[:nnz].cpu().numpy(), idx)
+        else:
+            assert np.array_equal(Pk.val[:2 * nnz].view(torch.int16).cpu().numpy().view(np.uint16), idx)
+    # padding: 16-byte aligned streams with >= 16 readable bytes behind the data
+    for t, used in ((Pk.col, nnz * (2, 4)[Pk.colmode]), (Pk.val, nnz * (1, 2, 8)[Pk.valmode])):
+        assert t.data_ptr() % 16 == 0 and t.numel() >= used + 16
+
+
+def test_distinct_value_set_limits_and_special_bit_patterns():
+    rng = np.random.default_rng(5)
+    PC = ops.PackedCSR
+    # exactly at the limit, one above it, and far above it (early exit)
+    for count, want in ((65536, 65536), (65537, None), (3_000_000, None)):
+        v = np.arange(1, count + 1, dtype=np.float64)
+        v = np.concatenate([v, v[rng.integers(0, count, 100000)]])
+        rng.shuffle(v)
+        u = PC._distinct_values(dev(v))
+        if want is None:
+            assert u is None
+        else:
+            assert np.array_equal(u.cpu().numpy(), np.unique(v.view(np.int64)))
+    # NaN payloads (including the all-ones pattern the table uses as its empty marker),
+    # infinities, signed zeros, denormals: compared as bit patterns
+    special = np.array([0x7FF8000000000000, 0xFFFFFFFFFFFFFFFF, 0x7FF8000000000001, 0x7FF0000000000000,
+                        0xFFF0000000000000, 0x0000000000000000, 0x8000000000000000, 0x0000000000000001],
+                       dtype=np.uint64).view(np.float64)
+    v = special[rng.integers(0, special.size, 50000)]
+    v[:special.size] = special
+    u = PC._distinct_values(dev(v))
+    assert np.array_equal(u.cpu().numpy(), np.unique(special.view(np.int64)))
+    out = torch.zeros(v.size + 32, dtype=torch.uint8, device=DEV)
+    PC._encode_values(dev(v), u, 1, out)
+    assert np.array_equal(out[:v.size].cpu().numpy(), np.searchsorted(np.unique(special.view(np.int64)), v.view(np.int64)))
+    # a dictionary that misses a value is reported, not silently mis-encoded
+    with pytest.raises(ops.LmgError):
+        PC._encode_values(dev(v), u[:-1].contiguous(), 1, out)
+    # many distinct values, dictionary too large for LDS (global binary search)
+    v = rng.integers(0, 40000, 500000).astype(np.float64) * 0.25 - 1000.0
+    u = PC._distinct_values(dev(v))
+    un = np.unique(v.view(np.int64))
+    assert np.array_equal(u.cpu().numpy(), un)
+    out = torch.zeros(2 * v.size + 32, dtype=torch.uint8, device=DEV)
+    PC._encode_values(dev(v), u, 2, out)
+    assert np.array_equal(out[:2 * v.size].view(torch.int16).cpu().numpy().view(np.uint16), np.searchsorted(un, v.view(np.int64)))
+
+
+def test_update_values_reencodes_or_asks_for_a_repack():
+    A = packed_case("val8_col16_poisson2d_513")
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    Pk = dA.pack()
+    assert Pk.valmode == 0
+    x = np.random.default_rng(3).standard_normal(A.shape[0])
+    B = A.copy()
+    B.data = np.where(B.data > 0, B.data * 3.0, B.data * 0.5)
+    dA.vals.copy_(dev(B.data))
+    dA.repack_values()
+    assert dA.packed is Pk and Pk.valmode == 0
+    y = torch.empty(A.shape[0], dtype=torch.float64, device=DEV)
+    ops.csr_spmv(dA, dev(x), y)
+    assert np.array_equal(y.cpu().numpy(), K.spmv(B, x, np.zeros(A.shape[0]), 1.0, 0.0))
+    # values that no longer fit a uint8 dictionary: full repack with another encoding
+    B.data = np.random.default_rng(4).standard_normal(B.nnz)
+    dA.vals.copy_(dev(B.data))
+    dA.repack_values()
+    assert dA.packed is not Pk and dA.packed.valmode == 2
+    ops.csr_spmv(dA, dev(x), y)
+    assert np.array_equal(y.cpu().numpy(), K.spmv(B, x, np.zeros(A.shape[0]), 1.0, 0.0))
+
+
+def test_inverse_diagonal_kernel():
+    rng = np.random.default_rng(9)
+    n = 5000
+    r, c = rng.integers(0, n, 50000), rng.integers(0, n, 50000)
+    off = sp.coo_matrix((rng.standard_normal(r.size)[r != c], (r[r != c], c[r != c])), shape=(n, n))
+    A = K.as_csr((off + sp.diags(rng.standard_normal(n))).tocsr())
+    # rows without a diagonal entry, with an explicit zero, and with duplicate diagonal entries
+    rp, ci, va = A.indptr.copy(), A.indices.copy(), A.data.copy()
+    for i in (3, 77):
+        seg = slice(rp[i], rp[i + 1])
+        va[seg] = np.where(ci[seg] == i, 0.0, va[seg])
+    extra_r, extra_c, extra_v = np.array([10, 10, 4999]), np.array([10, 10, 4999]), np.array([0.5, -0.25, 2.0])
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    rows, cols, vals = np.concatenate([rows, extra_r]), np.concatenate([ci, extra_c]), np.concatenate([va, extra_v])
+    keep = ~((rows == 200) & (cols == 200))
+    rows, cols, vals = rows[keep], cols[keep], vals[keep]
+    order = np.argsort(rows, kind="stable")              # duplicates stay unmerged, storage order kept
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    rp2 = np.zeros(n + 1, dtype=np.int32)
+    np.add.at(rp2, rows + 1, 1)
+    rp2 = np.cumsum(rp2).astype(np.int32)
+    dA = ops.DeviceCSR(dev(rp2), dev(cols.astype(np.int32)), dev(vals), (n, n))
+    got = ops.csr_inverse_diagonal(dA).cpu().numpy()
+    want = np.zeros(n)
+    for i in range(n):
+        d = 0.0
+        for e in range(rp2[i], rp2[i + 1]):
+            if cols[e] == i:
+                d += vals[e]
+        want[i] = 1.0 / d if d != 0.0 else 0.0
+    assert np.array_equal(got, want)
+    assert want[3] == 0.0 and want[77] == 0.0 and want[200] == 0.0

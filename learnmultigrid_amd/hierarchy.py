@@ -72,21 +72,14 @@ class Hierarchy:
         self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         A0 = A if isinstance(A, DeviceCSR) else DeviceCSR.from_scipy(A, self.device)
         self.levels = [Level(A0)]
-        if isinstance(A, DeviceCSR):
-            self.levels[0].host_pattern = None
-        else:
-            Ah = _to_csr_host(A)
-            self.levels[0].host_pattern = (Ah.indptr.astype(np.int32), Ah.indices.astype(np.int32))
         for P in transfers:
             lev = self.levels[-1]
             Ph = _to_csr_host(P)
             if Ph.shape[0] != lev.n:
                 raise ValueError("transfer operator of level %d has %d rows, level has %d unknowns"
                                  % (len(self.levels) - 1, Ph.shape[0], lev.n))
-            Rh = Ph.T.tocsr()
-            Rh.sort_indices()
             lev.P = DeviceCSR.from_scipy(Ph, self.device)
-            lev.R = DeviceCSR.from_scipy(Rh, self.device)
+            lev.R = lev.P.transpose()
             lev.plan_RA = ops_.SpGEMMPlan(lev.R, lev.A)
             lev.RA = lev.plan_RA.numeric(lev.R, lev.A)
             lev.plan_RAP = ops_.SpGEMMPlan(lev.RA, lev.P)

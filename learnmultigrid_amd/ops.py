@@ -79,6 +79,20 @@ class DeviceCSR:
                    torch.from_numpy(A.indices.astype(np.int32)).to(device),
                    torch.from_numpy(np.ascontiguousarray(A.data)).to(device), A.shape)
 
+    def transpose(self):
+        """A^T as a sorted CSR on the same device (setup: R = P^T).  A stable sort by column
+        keeps the row order inside every column, i.e. the result is what SciPy's
+        `A.T.tocsr()` gives for a canonical A."""
+        n, m = self.shape
+        dev = self.vals.device
+        rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=I32),
+                                       (self.rowptr[1:] - self.rowptr[:-1]).long())
+        order = torch.sort(self.colidx, stable=True).indices
+        rp = torch.zeros(m + 1, dtype=I32, device=dev)
+        if self.nnz:
+            rp[1:] = torch.cumsum(torch.bincount(self.colidx, minlength=m), 0).to(I32)
+        return DeviceCSR(rp, rows[order].contiguous(), self.vals[order].contiguous(), (m, n))
+
     def to_scipy(self):
         import scipy.sparse as sp
         return sp.csr_matrix((self.vals.cpu().numpy(), self.colidx.cpu().numpy(),

@@ -205,6 +205,26 @@ int lmg_spgemm_numeric(int64_t a_rows, const int32_t *d_a_rowptr, const int32_t 
                        const int32_t *d_row_products, int32_t max_products,
                        const int32_t *d_c_rowptr, int32_t *d_c_colidx, double *d_c_vals,
                        void *stream);
+/* Numeric passes on a RECORDED pattern (coefficient changes on a fixed sparsity pattern:
+ * the Galerkin rebuild).  lmg_spgemm_numeric_record is lmg_spgemm_numeric that also stores, for
+ * every product, its position in the sorted product list of its row (d_dst, uint16, indexed
+ * d_prod_ptr[row] + traversal sequence number; d_prod_ptr = exclusive int64 scan of
+ * d_row_products with the long rows counted as 0) and the end of every C entry's segment in that
+ * list (d_segend[nnz(C)], uint16).  lmg_spgemm_numeric_replay then recomputes d_c_vals without
+ * sorting -- same products, same order of additions, bit-identical values -- at 2 bytes of
+ * extra traffic per product.  d_c_colidx is not touched by the replay. */
+int lmg_spgemm_numeric_record(int64_t a_rows, const int32_t *d_a_rowptr, const int32_t *d_a_colidx,
+                              const double *d_a_vals, const int32_t *d_b_rowptr,
+                              const int32_t *d_b_colidx, const double *d_b_vals,
+                              const int32_t *d_row_products, int32_t max_products,
+                              const int32_t *d_c_rowptr, int32_t *d_c_colidx, double *d_c_vals,
+                              const int64_t *d_prod_ptr, uint16_t *d_dst, uint16_t *d_segend,
+                              void *stream);
+int lmg_spgemm_numeric_replay(int64_t a_rows, const int32_t *d_a_rowptr, const int32_t *d_a_colidx,
+                              const double *d_a_vals, const int32_t *d_b_rowptr, const double *d_b_vals,
+                              const int32_t *d_row_products, int32_t max_products,
+                              const int32_t *d_c_rowptr, double *d_c_vals, const int64_t *d_prod_ptr,
+                              const uint16_t *d_dst, const uint16_t *d_segend, void *stream);
 int lmg_spgemm_long_rows(int numeric, int64_t nlong, const int32_t *d_long_rows,
                          const int32_t *d_a_rowptr, const int32_t *d_a_colidx, const double *d_a_vals,
                          const int32_t *d_b_rowptr, const int32_t *d_b_colidx, const double *d_b_vals,

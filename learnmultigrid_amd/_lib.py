@@ -57,6 +57,8 @@ SIGNATURES = {
     "lmg_spgemm_count": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p]),
     "lmg_spgemm_symbolic": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _i32, _p, _p]),
     "lmg_spgemm_numeric": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
+    "lmg_spgemm_numeric_record": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "lmg_spgemm_numeric_replay": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p]),
     "lmg_spgemm_long_rows": (_c.c_int, [_c.c_int, _i64, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "lmg_scan_scratch_count": (_i64, [_i64]),
     "lmg_exclusive_scan_i32": (_c.c_int, [_i64, _p, _p, _p, _p]),

@@ -105,8 +105,13 @@ class DenseInverse:
         n = A.shape[0]
         if n > MAX_DENSE:
             raise ValueError("coarsest level has %d unknowns (> %d): use more levels" % (n, MAX_DENSE))
-        self.inv = dense_inverse(csr_to_dense(A))
         self.n = n
+        self.factor(A)
+
+    def factor(self, A):
+        if A.shape[0] != self.n:
+            raise ValueError("coarse operator changed its size")
+        self.inv = dense_inverse(csr_to_dense(A))
 
     def apply(self, b, x):
         self.ops.dense_gemv(self.inv, b, x)
@@ -143,53 +148,136 @@ class BandedBlockSolver:
 
     def __init__(self, A, ops_mod, k, s):
         self.ops = ops_mod
+        self._symbolic(A, k, s)
+        self.factor(A)
+
+    # ---- symbolic: index sets and entry maps, once per sparsity pattern (host) ----------
+    def _symbolic(self, A, k, s):
         dev = A.device
         n = A.shape[0]
-        Ah = sp.csr_matrix((A.vals.cpu().numpy(), A.colidx.cpu().numpy(), A.rowptr.cpu().numpy()), shape=A.shape)
-        w = half_bandwidth(Ah)
+        rp, ci = A.rowptr.cpu().numpy(), A.colidx.cpu().numpy()
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))
+        cols = ci.astype(np.int64)
+        w = int(np.abs(rows - cols).max()) if cols.size else 0
         ns = n - k * s                                # all separator unknowns
         base, extra = divmod(ns, k - 1)               # separator sizes, each >= w
         if base < w:
             raise ValueError("separators thinner than the bandwidth")
-        strips, seps, pos = [], [], 0
+        strips, seps, sep_off, pos = [], [], [0], 0
         for i in range(k):
             strips.append(np.arange(pos, pos + s))
             pos += s
             if i < k - 1:
                 sz = base + (1 if i < extra else 0)
                 seps.append(np.arange(pos, pos + sz))
+                sep_off.append(sep_off[-1] + sz)
                 pos += sz
         assert pos == n
         I = np.concatenate(strips)
         S = np.concatenate(seps)
-        self.n, self.nI, self.nS, self.k, self.s, self.w = n, I.size, S.size, k, s, w
+        nI, nS = I.size, S.size
+        self.n, self.nI, self.nS, self.k, self.s, self.w = n, nI, nS, k, s, w
         perm = np.concatenate([I, S])
-        A_II = Ah[I][:, I].tocsr()
+        inv = np.empty(n, dtype=np.int64)
+        inv[perm] = np.arange(n)
+        pr, pc = inv[rows], inv[cols]                 # permuted coordinates of every entry
+        eid = np.arange(cols.size, dtype=np.int64)
+        rI, cI = pr < nI, pc < nI
         # strips must be mutually decoupled: A_II is block diagonal with s x s blocks
-        coo = A_II.tocoo()
-        if coo.nnz and np.any(coo.row // s != coo.col // s):
+        m = rI & cI
+        if np.any(pr[m] // s != pc[m] // s):
             raise ValueError("strips are coupled: the operator is not banded in this ordering")
-        A_IS = Ah[I][:, S].tocsr()
-        A_SI = Ah[S][:, I].tocsr()
-        A_SS = Ah[S][:, S].toarray()
-        blocks = torch.empty((k, s, s), dtype=F64, device=dev)
-        for i in range(k):
-            blk = A_II[i * s:(i + 1) * s, i * s:(i + 1) * s].toarray()
-            blocks[i] = dense_inverse(torch.from_numpy(blk).to(dev))
-        self.blocks = blocks.contiguous()
-        # Schur complement S = A_SS - A_SI A_II^-1 A_IS, strip by strip (dense GEMMs, setup only)
-        Sc = torch.from_numpy(A_SS).to(dev)
-        for i in range(k):
-            rows = slice(i * s, (i + 1) * s)
-            Ais = torch.from_numpy(A_IS[rows].toarray()).to(dev)            # s x nS
-            Asi = torch.from_numpy(A_SI[:, rows].toarray()).to(dev)         # nS x s
-            Sc -= Asi @ (self.blocks[i] @ Ais)
-        self.Sinv = dense_inverse(Sc)
-        self.A_IS = DeviceCSR.from_scipy(A_IS, dev)
-        self.A_SI = DeviceCSR.from_scipy(A_SI, dev)
-        self.perm = torch.from_numpy(perm.astype(np.int32)).to(dev)
-        z = lambda m: torch.zeros(m, dtype=F64, device=dev)
-        self.bp, self.xp, self.y, self.t = z(n), z(n), z(self.nI), z(self.nI)
+        # window of separator unknowns a strip couples to: separators i-1 and i (contiguous in S)
+        sep_off = np.asarray(sep_off, dtype=np.int64)
+        ws = np.array([sep_off[max(i - 1, 0)] for i in range(k)], dtype=np.int64)
+        we = np.array([sep_off[min(i + 1, k - 1)] for i in range(k)], dtype=np.int64)
+        cw = int((we - ws).max())
+        self.cw = cw
+        t = lambda a, dt=torch.int64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+        self._src_II = t(eid[m])
+        self._dst_II = t((pr[m] // s) * s * s + (pr[m] % s) * s + (pc[m] % s))
+        m = rI & ~cI                                  # A_IS: strip rows x separator columns
+        strip = pr[m] // s
+        loc = (pc[m] - nI) - ws[strip]
+        if np.any(loc < 0) or np.any(loc >= (we - ws)[strip]):
+            raise ValueError("a strip couples to a distant separator: not banded in this ordering")
+        self._src_IS = t(eid[m])
+        self._dst_IS = t(strip * s * cw + (pr[m] % s) * cw + loc)
+        IS_pat = sp.csr_matrix((eid[m] + 1.0, (pr[m], pc[m] - nI)), shape=(nI, nS))
+        m = ~rI & cI                                  # A_SI: separator rows x strip columns
+        strip = pc[m] // s
+        loc = (pr[m] - nI) - ws[strip]
+        if np.any(loc < 0) or np.any(loc >= (we - ws)[strip]):
+            raise ValueError("a strip couples to a distant separator: not banded in this ordering")
+        self._src_SI = t(eid[m])
+        self._dst_SI = t(strip * cw * s + loc * s + (pc[m] % s))
+        SI_pat = sp.csr_matrix((eid[m] + 1.0, (pr[m] - nI, pc[m])), shape=(nS, nI))
+        m = ~rI & ~cI
+        self._src_SS = t(eid[m])
+        self._dst_SS = t((pr[m] - nI) * nS + (pc[m] - nI))
+        # where the k local Schur updates land in S (flat indices, padded entries masked out)
+        ar = np.arange(cw, dtype=np.int64)
+        gi = ws[:, None, None] + ar[None, :, None]
+        gj = ws[:, None, None] + ar[None, None, :]
+        ok = (gi < we[:, None, None]) & (gj < we[:, None, None])
+        flat = np.arange(k * cw * cw, dtype=np.int64).reshape(k, cw, cw)
+        dst = gi * nS + gj
+        # strips i and i+1 both update separator i: even strips first, then odd ones, so every
+        # pass writes each entry of S at most once (fixed order of additions => reproducible bits)
+        self._upd = []
+        for parity in (0, 1):
+            sel = ok.copy()
+            sel[np.arange(k) % 2 != parity] = False
+            self._upd.append((t(flat[sel]), t(dst[sel])))
+        # sparse off-diagonal blocks for apply(): CSR patterns once, values refreshed by factor()
+        self._IS_src = t(np.rint(IS_pat.data).astype(np.int64) - 1)
+        self._SI_src = t(np.rint(SI_pat.data).astype(np.int64) - 1)
+        z64 = lambda m_: torch.zeros(m_, dtype=F64, device=dev)
+        self.A_IS = DeviceCSR(t(IS_pat.indptr, torch.int32), t(IS_pat.indices, torch.int32), z64(IS_pat.nnz), (nI, nS))
+        self.A_SI = DeviceCSR(t(SI_pat.indptr, torch.int32), t(SI_pat.indices, torch.int32), z64(SI_pat.nnz), (nS, nI))
+        self.perm = t(perm, torch.int32)
+        self.bp, self.xp, self.y, self.t = z64(n), z64(n), z64(nI), z64(nI)
+        self.blocks = torch.zeros((k, s, s), dtype=F64, device=dev)
+        self.Sinv = None
+        self._nnz = int(cols.size)
+
+    # ---- numeric: device only (repeated for every Galerkin rebuild) -----------------------
+    def factor(self, A):
+        """Strip inverses, Schur complement S = A_SS - A_SI A_II^-1 A_IS and S^-1 from the
+        current values of A (same pattern as at construction)."""
+        if A.nnz != self._nnz:
+            raise ValueError("coarse operator changed its sparsity pattern")
+        k, s, cw, nS = self.k, self.s, self.cw, self.nS
+        dev = A.vals.device
+        v = A.vals
+        dense = torch.zeros(k * s * s, dtype=F64, device=dev)
+        dense.index_put_((self._dst_II,), v[self._src_II], accumulate=True)
+        dense = dense.view(k, s, s)
+        inv = None
+        try:
+            inv = torch.linalg.inv(dense)
+            eye = torch.eye(s, dtype=F64, device=dev)
+            ok = bool(torch.isfinite(inv).all()) and float((eye - torch.bmm(dense, inv)).abs().max()) < 1e-9
+        except RuntimeError:
+            ok = False
+        if not ok:                                    # robust path, strip by strip
+            inv = torch.stack([dense_inverse(dense[i].contiguous()) for i in range(k)])
+        self.blocks = inv.contiguous()
+        ais = torch.zeros(k * s * cw, dtype=F64, device=dev)
+        ais.index_put_((self._dst_IS,), v[self._src_IS], accumulate=True)
+        asi = torch.zeros(k * cw * s, dtype=F64, device=dev)
+        asi.index_put_((self._dst_SI,), v[self._src_SI], accumulate=True)
+        upd = torch.bmm(asi.view(k, cw, s), torch.bmm(self.blocks, ais.view(k, s, cw)))      # k x cw x cw
+        Sc = torch.zeros(nS * nS, dtype=F64, device=dev)
+        Sc.index_put_((self._dst_SS,), v[self._src_SS], accumulate=True)
+        upd = upd.reshape(-1)
+        for sel, dst in self._upd:
+            Sc.index_put_((dst,), -upd[sel], accumulate=True)
+        self.Sinv = dense_inverse(Sc.view(nS, nS))
+        self.A_IS.vals.copy_(v[self._IS_src])
+        self.A_SI.vals.copy_(v[self._SI_src])
+        self.A_IS.invalidate_packed()
+        self.A_SI.invalidate_packed()
 
     def apply(self, b, x):
         o = self.ops

@@ -108,10 +108,14 @@ __global__ void __launch_bounds__(256) count_products_kernel(int64_t a_rows, con
     if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(max_products, m);
 }
 
-template <int BLOCK, int CAP, bool NUMERIC>
+// RECORD (numeric only): also store where every product went -- dst[prod_ptr[row] + sequence
+// number] = its position in the sorted list -- and where the segment of every C entry ends, so
+// that later numeric passes on the same pattern can skip the sort (spgemm_replay_kernel).
+template <int BLOCK, int CAP, bool NUMERIC, bool RECORD = false>
 __global__ void __launch_bounds__(BLOCK) spgemm_row_kernel(
     int64_t a_rows, const int *Ap, const int *Aj, const double *Ax, const int *Bp, const int *Bj,
-    const double *Bx, const int *row_products, int *c_rownnz, const int *Cp, int *Cj, double *Cx)
+    const double *Bx, const int *row_products, int *c_rownnz, const int *Cp, int *Cj, double *Cx,
+    const int64_t *prod_ptr = nullptr, uint16_t *dst = nullptr, uint16_t *segend = nullptr)
 {
     using KEY = typename std::conditional<NUMERIC, unsigned long long, unsigned int>::type;
     constexpr KEY kPad = ~(KEY)0;
@@ -159,6 +163,11 @@ __global__ void __launch_bounds__(BLOCK) spgemm_row_kernel(
         __syncthreads();
         // ---- sort -------------------------------------------------------------------
         bitonic_sort_lds<BLOCK, KEY, NUMERIC>(s_key, s_val, m);
+        if (RECORD) {
+            const int64_t pb = prod_ptr[row];
+            for (int p = threadIdx.x; p < np; p += BLOCK)
+                dst[pb + (unsigned)((unsigned long long)s_key[p] & 0xFFFFFFFFull)] = (uint16_t)p;
+        }
         // ---- compress ---------------------------------------------------------------
         int base_out = 0;
         for (int p0 = 0; p0 < np; p0 += BLOCK) {
@@ -186,10 +195,57 @@ __global__ void __launch_bounds__(BLOCK) spgemm_row_kernel(
                 const int o = Cp[row] + rank;
                 Cj[o] = (int)col;
                 Cx[o] = sum;
+                if (RECORD) segend[o] = (uint16_t)q;
             }
             base_out += nheads;
         }
         if (!NUMERIC && threadIdx.x == 0) c_rownnz[row] = base_out;
+    }
+}
+
+// ---- numeric pass on a recorded pattern ------------------------------------------------------
+// Same expand step, but every product is written straight to its recorded sorted position; a C
+// entry then is the in-order sum of one contiguous LDS range.  No sort, one barrier per row:
+// the pass streams 2 B per product + the operands and is bound by HBM / L2, not by LDS sorting.
+template <int BLOCK, int CAP>
+__global__ void __launch_bounds__(BLOCK) spgemm_replay_kernel(
+    int64_t a_rows, const int *Ap, const int *Aj, const double *Ax, const int *Bp, const double *Bx,
+    const int *row_products, const int *Cp, double *Cx, const int64_t *prod_ptr, const uint16_t *dst,
+    const uint16_t *segend)
+{
+    __shared__ double s_val[CAP];
+    __shared__ int s_w[BLOCK / LMG_WAVE + 1];
+    for (int64_t row = blockIdx.x; row < a_rows; row += gridDim.x) {
+        const int np = row_products[row];
+        if (np == 0 || np > CAP) continue;
+        const int a_s = Ap[row], a_e = Ap[row + 1];
+        const uint16_t *d = dst + prod_ptr[row];
+        __syncthreads();          // previous row fully consumed
+        int done = 0;
+        for (int c0 = a_s; c0 < a_e; c0 += BLOCK) {
+            const int jj = c0 + (int)threadIdx.x;
+            int bs = 0, len = 0;
+            double av = 0.0;
+            if (jj < a_e) {
+                const int j = Aj[jj];
+                bs = Bp[j];
+                len = Bp[j + 1] - bs;
+                av = Ax[jj];
+            }
+            int chunk_total;
+            const int off = done + block_excl_scan<BLOCK>(len, s_w, &chunk_total);
+            for (int kk = 0; kk < len; ++kk) s_val[d[off + kk]] = av * Bx[bs + kk];
+            done += chunk_total;
+        }
+        __syncthreads();
+        const int c_s = Cp[row], c_n = Cp[row + 1] - c_s;
+        for (int e = threadIdx.x; e < c_n; e += BLOCK) {
+            int q = e ? (int)segend[c_s + e - 1] : 0;
+            const int q_end = (int)segend[c_s + e];
+            double sum = 0.0;
+            for (; q < q_end; ++q) sum += s_val[q];
+            Cx[c_s + e] = sum;
+        }
     }
 }
 
@@ -273,9 +329,77 @@ int launch_rows(int64_t a_rows, const int *Ap, const int *Aj, const double *Ax, 
     return LMG_OK;
 }
 
+int launch_record(int64_t a_rows, const int *Ap, const int *Aj, const double *Ax, const int *Bp,
+                  const int *Bj, const double *Bx, const int *row_products, int max_products,
+                  const int *Cp, int *Cj, double *Cx, const int64_t *prod_ptr, uint16_t *dst,
+                  uint16_t *segend, hipStream_t st)
+{
+    if (a_rows == 0) return LMG_OK;
+    if (max_products > LMG_SPGEMM_MAX_ROW_PRODUCTS) max_products = LMG_SPGEMM_MAX_ROW_PRODUCTS;
+    int64_t g = a_rows;
+    if (max_products <= 128) {
+        if (g > 256 * 32) g = 256 * 32;
+        hipLaunchKernelGGL((spgemm_row_kernel<64, 128, true, true>), dim3((unsigned)g), dim3(64), 0, st, a_rows,
+                           Ap, Aj, Ax, Bp, Bj, Bx, row_products, nullptr, Cp, Cj, Cx, prod_ptr, dst, segend);
+    } else if (max_products <= 1024) {
+        if (g > 256 * 10) g = 256 * 10;
+        hipLaunchKernelGGL((spgemm_row_kernel<64, 1024, true, true>), dim3((unsigned)g), dim3(64), 0, st, a_rows,
+                           Ap, Aj, Ax, Bp, Bj, Bx, row_products, nullptr, Cp, Cj, Cx, prod_ptr, dst, segend);
+    } else {
+        if (g > 256 * 2) g = 256 * 2;
+        hipLaunchKernelGGL((spgemm_row_kernel<256, 8192, true, true>), dim3((unsigned)g), dim3(256), 0, st, a_rows,
+                           Ap, Aj, Ax, Bp, Bj, Bx, row_products, nullptr, Cp, Cj, Cx, prod_ptr, dst, segend);
+    }
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+template <int BLOCK, int CAP>
+void launch_replay_class(int64_t a_rows, int per_cu, const int *Ap, const int *Aj, const double *Ax, const int *Bp,
+                         const double *Bx, const int *row_products, const int *Cp, double *Cx,
+                         const int64_t *prod_ptr, const uint16_t *dst, const uint16_t *segend, hipStream_t st)
+{
+    int64_t g = a_rows;
+    if (g > 256 * (int64_t)per_cu) g = 256 * (int64_t)per_cu;
+    hipLaunchKernelGGL((spgemm_replay_kernel<BLOCK, CAP>), dim3((unsigned)g), dim3(BLOCK), 0, st, a_rows, Ap, Aj,
+                       Ax, Bp, Bx, row_products, Cp, Cx, prod_ptr, dst, segend);
+}
+
 }  // namespace
 
 extern "C" {
+
+int lmg_spgemm_numeric_record(int64_t a_rows, const int32_t *Ap, const int32_t *Aj, const double *Ax,
+                              const int32_t *Bp, const int32_t *Bj, const double *Bx,
+                              const int32_t *row_products, int32_t max_products, const int32_t *Cp,
+                              int32_t *Cj, double *Cx, const int64_t *prod_ptr, uint16_t *dst,
+                              uint16_t *segend, void *stream)
+{
+    if (a_rows < 0 || !Ap || !Bp || !row_products || !Cp || !prod_ptr || !dst || !segend) return LMG_ERR_ARG;
+    return launch_record(a_rows, Ap, Aj, Ax, Bp, Bj, Bx, row_products, max_products, Cp, Cj, Cx, prod_ptr, dst,
+                         segend, lmg_stream(stream));
+}
+
+int lmg_spgemm_numeric_replay(int64_t a_rows, const int32_t *Ap, const int32_t *Aj, const double *Ax,
+                              const int32_t *Bp, const double *Bx, const int32_t *row_products,
+                              int32_t max_products, const int32_t *Cp, double *Cx, const int64_t *prod_ptr,
+                              const uint16_t *dst, const uint16_t *segend, void *stream)
+{
+    if (a_rows < 0 || !Ap || !Bp || !row_products || !Cp || !prod_ptr || !dst || !segend) return LMG_ERR_ARG;
+    if (a_rows == 0) return LMG_OK;
+    hipStream_t st = lmg_stream(stream);
+    if (max_products > LMG_SPGEMM_MAX_ROW_PRODUCTS) max_products = LMG_SPGEMM_MAX_ROW_PRODUCTS;
+    if (max_products <= 128)
+        launch_replay_class<64, 128>(a_rows, 32, Ap, Aj, Ax, Bp, Bx, row_products, Cp, Cx, prod_ptr, dst, segend, st);
+    else if (max_products <= 512)
+        launch_replay_class<64, 512>(a_rows, 32, Ap, Aj, Ax, Bp, Bx, row_products, Cp, Cx, prod_ptr, dst, segend, st);
+    else if (max_products <= 2048)
+        launch_replay_class<128, 2048>(a_rows, 8, Ap, Aj, Ax, Bp, Bx, row_products, Cp, Cx, prod_ptr, dst, segend, st);
+    else
+        launch_replay_class<256, 8192>(a_rows, 2, Ap, Aj, Ax, Bp, Bx, row_products, Cp, Cx, prod_ptr, dst, segend, st);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
 
 int lmg_spgemm_count(int64_t a_rows, const int32_t *Ap, const int32_t *Aj, const int32_t *Bp,
                      int32_t *row_products, int32_t *max_products, void *stream)

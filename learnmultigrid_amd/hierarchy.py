@@ -117,7 +117,15 @@ class Hierarchy:
     def _factor_coarsest(self):
         """Direct solver of the coarsest operator (setup): dense inverse, or the banded block
         elimination of coarse.py when the operator is narrow-banded (grid problems)."""
-        self.coarse = make_coarse_solver(self.levels[-1].A, self.ops, self.coarse_strategy)
+        A = self.levels[-1].A
+        old = getattr(self, "coarse", None)
+        if old is not None and hasattr(old, "factor") and old.n == A.shape[0]:
+            try:
+                old.factor(A)                          # same pattern: numeric phase only
+                return
+            except ValueError:
+                pass
+        self.coarse = make_coarse_solver(A, self.ops, self.coarse_strategy)
 
     def rebuild_numeric(self, new_vals):
         """Galerkin rebuild after the VALUES of the fine matrix changed (same pattern):

@@ -110,8 +110,8 @@ class PackedCSR:
     """Lossless packed twin of a DeviceCSR for lmg_pcsr_sweep (see include/lmg.h):
     uint8 row lengths, uint16 tile-relative columns when every 512-row tile spans < 65536
     columns, and a value dictionary (uint8 / uint16 indices) when the matrix has few
-    distinct values -- compared BITWISE, so -0.0 / NaN payloads survive.  Built with torch
-    ops at setup (format conversion, like SciPy's csc -> csr); the sweeps are the HIP kernel."""
+    distinct values -- compared BITWISE, so -0.0 / NaN payloads survive.  Built at setup by the
+    kernels of csrc/pack.hip (format conversion, like SciPy's csc -> csr)."""
 
     __slots__ = ("n", "nnz", "shape", "tile_rows", "tile_cap", "tile_base", "tile_colbase", "rowlen", "col",
                  "colmode", "val", "valmode", "dict", "ndict", "bytes_")
@@ -434,12 +434,26 @@ SPGEMM_MAX_ROW_PRODUCTS = 8192       # LMG_SPGEMM_MAX_ROW_PRODUCTS
 _LONG_ROW_SETS = 32
 
 
+SPGEMM_RECORD_MAX_BYTES = 64 << 30   # upper limit of one plan's recorded product map
+
+
 class SpGEMMPlan:
     """Symbolic result of C = A*B (pattern of C + per-row product counts); `numeric`
     can be re-run when only the values of A or B changed (Galerkin rebuild).  Rows that
-    need more products than the LDS kernels hold go through lmg_spgemm_long_rows."""
+    need more products than the LDS kernels hold go through lmg_spgemm_long_rows.
 
-    def __init__(self, A, B):
+    record: "lazy" (default) -- the first RE-run of `numeric` also records where every product
+    lands (2 B per product, lmg_spgemm_numeric_record) and all later runs replay that map
+    without sorting; True -- record on the first run already; False -- always sort.  The map is
+    only kept when it fits SPGEMM_RECORD_MAX_BYTES and half of the free device memory."""
+
+    def __init__(self, A, B, record="lazy"):
+        self.record = record
+        self._runs = 0
+        self._rec = None             # (prod_ptr, dst, segend, c_colidx)
+        self._init_symbolic(A, B)
+
+    def _init_symbolic(self, A, B):
         if A.shape[1] != B.shape[0]:
             raise ValueError("spgemm shape mismatch %s x %s" % (A.shape, B.shape))
         dev = A.device
@@ -474,19 +488,67 @@ class SpGEMMPlan:
             _p(out.rowptr) if out is not None else None, _p(out.colidx) if out is not None else None,
             _p(out.vals) if out is not None else None, _s()), "lmg_spgemm_long_rows")
 
+    def _record_buffers(self, dev):
+        """Buffers of the product map, or None when recording is off / does not fit."""
+        n = self.shape[0]
+        short = torch.where(self.row_products[:n] <= SPGEMM_MAX_ROW_PRODUCTS, self.row_products[:n],
+                            torch.zeros_like(self.row_products[:n])).long()
+        incl = torch.cumsum(short, 0)
+        total = int(incl[-1]) if n else 0
+        need = 2 * total + 2 * self.c_nnz + 8 * n
+        limit = SPGEMM_RECORD_MAX_BYTES
+        if dev.type == "cuda":
+            limit = min(limit, torch.cuda.mem_get_info(dev)[0] // 2)
+        if total == 0 or need > limit:
+            return None
+        prod_ptr = (incl - short).contiguous()
+        return (prod_ptr, torch.empty(total, dtype=torch.int16, device=dev),
+                torch.zeros(max(self.c_nnz, 1), dtype=torch.int16, device=dev))
+
     def numeric(self, A, B, out=None):
         dev = A.device
+        L = _lib.lib()
+        self._runs += 1
+        if self._rec is not None:
+            prod_ptr, dst, segend, c_colidx = self._rec
+            if out is None:
+                out = DeviceCSR(self.c_rowptr, c_colidx, torch.empty(self.c_nnz, dtype=F64, device=dev), self.shape)
+            elif out.colidx is not c_colidx:
+                out.colidx.copy_(c_colidx)
+            check(L.lmg_spgemm_numeric_replay(A.shape[0], _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(B.rowptr),
+                                              _p(B.vals), _p(self.row_products), self.max_products, _p(out.rowptr),
+                                              _p(out.vals), _p(prod_ptr), _p(dst), _p(segend), _s()),
+                  "lmg_spgemm_numeric_replay")
+            if self.long_rows is not None:
+                self._long(True, A, B, None, out)
+            return out
         if out is None:
             out = DeviceCSR(self.c_rowptr, torch.empty(self.c_nnz, dtype=I32, device=dev),
                             torch.empty(self.c_nnz, dtype=F64, device=dev), self.shape)
-        check(_lib.lib().lmg_spgemm_numeric(A.shape[0], _p(A.rowptr), _p(A.colidx), _p(A.vals),
-                                            _p(B.rowptr), _p(B.colidx), _p(B.vals),
-                                            _p(self.row_products), self.max_products,
-                                            _p(out.rowptr), _p(out.colidx), _p(out.vals), _s()),
-              "lmg_spgemm_numeric")
+        bufs = None
+        if self.record is True or (self.record == "lazy" and self._runs >= 2):
+            bufs = self._record_buffers(dev)
+            if bufs is None:
+                self.record = False                      # does not fit: stop asking
+        if bufs is not None:
+            prod_ptr, dst, segend = bufs
+            check(L.lmg_spgemm_numeric_record(A.shape[0], _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(B.rowptr),
+                                              _p(B.colidx), _p(B.vals), _p(self.row_products), self.max_products,
+                                              _p(out.rowptr), _p(out.colidx), _p(out.vals), _p(prod_ptr), _p(dst),
+                                              _p(segend), _s()), "lmg_spgemm_numeric_record")
+            self._rec = (prod_ptr, dst, segend, out.colidx)
+        else:
+            check(L.lmg_spgemm_numeric(A.shape[0], _p(A.rowptr), _p(A.colidx), _p(A.vals),
+                                       _p(B.rowptr), _p(B.colidx), _p(B.vals),
+                                       _p(self.row_products), self.max_products,
+                                       _p(out.rowptr), _p(out.colidx), _p(out.vals), _s()),
+                  "lmg_spgemm_numeric")
         if self.long_rows is not None:
             self._long(True, A, B, None, out)
         return out
+
+    def recorded_bytes(self):
+        return 0 if self._rec is None else sum(int(t.numel()) * t.element_size() for t in self._rec[:3])
 
 
 def spgemm(A, B):

@@ -54,6 +54,33 @@ def test_banded_block_solver_matches_superlu():
     assert np.linalg.norm(y.numpy() - want) / np.linalg.norm(want) < 1e-11
 
 
+def test_refactor_with_new_values_on_the_same_pattern():
+    Ac = galerkin_operator(64)
+    n = Ac.shape[0]
+    dA = DeviceCSR.from_scipy(Ac, "cpu")
+    for strategy in ("banded", "dense"):
+        solver = coarse.make_coarse_solver(dA, shim, strategy)
+        rng = np.random.default_rng(5)
+        A2 = Ac.copy()
+        A2.data = A2.data * (1.0 + 0.2 * rng.random(A2.nnz))       # same pattern, other coefficients
+        solver.factor(DeviceCSR.from_scipy(A2, "cpu"))
+        b = rng.standard_normal(n)
+        x = torch.zeros(n, dtype=torch.float64)
+        solver.apply(torch.from_numpy(b.copy()), x)
+        want = spla.spsolve(sp.csc_matrix(A2), b)
+        assert np.linalg.norm(x.numpy() - want) / np.linalg.norm(want) < 1e-11, strategy
+        fresh = coarse.make_coarse_solver(DeviceCSR.from_scipy(A2, "cpu"), shim, strategy)
+        y = torch.zeros(n, dtype=torch.float64)
+        fresh.apply(torch.from_numpy(b.copy()), y)
+        assert torch.equal(x, y)                                   # refactoring == building anew
+    with_other_pattern = DeviceCSR.from_scipy(galerkin_operator(48), "cpu")
+    try:
+        coarse.make_coarse_solver(dA, shim, "banded").factor(with_other_pattern)
+        raise AssertionError("pattern change must be refused")
+    except ValueError:
+        pass
+
+
 def test_unstructured_numbering_falls_back_to_dense():
     Ac = galerkin_operator(24)                       # 25^2 = 625 < 2048 -> dense by size
     assert coarse.make_coarse_solver(DeviceCSR.from_scipy(Ac, "cpu"), shim).kind == "dense"

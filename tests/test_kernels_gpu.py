@@ -247,8 +247,8 @@ def test_exclusive_scan_bit_exact(n):
     assert np.array_equal(out.cpu().numpy().astype(np.int64), want)
 
 
-SPGEMM = ["RA_2d", "RA_P_2d", "QtA_l2like", "QtAQ_l2like", "RA_1d", "ragged_sq", "ragged_medium",
-          "empty_rows"]
+SPGEMM = ["RA_2d", "RA_P_2d", "QtA_l2like", "QtAQ_l2like", "QtA_level1_l2like", "RA_1d", "ragged_sq",
+          "ragged_medium", "empty_rows"]
 
 
 @functools.lru_cache(maxsize=None)
@@ -262,6 +262,12 @@ def spgemm_case(name):
                                         P.pseudo_l2_interpolator_1d(65)).tocsr(), 43)
         R = Pm.T.tocsr()
         return (R, A2) if name in ("RA_2d", "QtA_l2like") else (sp.csr_matrix(R @ A2), Pm)
+    if name == "QtA_level1_l2like":              # 25-entry R rows x 25-entry Galerkin rows: ~600 products per row
+        A2, _ = P.poisson_2d_structured(64)
+        Q0 = P.learned_like(sp.kron(P.pseudo_l2_interpolator_1d(65), P.pseudo_l2_interpolator_1d(65)).tocsr(), 43)
+        A1 = sp.csr_matrix(Q0.T @ A2 @ Q0)
+        Q1 = P.learned_like(sp.kron(P.pseudo_l2_interpolator_1d(33), P.pseudo_l2_interpolator_1d(33)).tocsr(), 44)
+        return Q1.T.tocsr(), A1
     if name == "RA_1d":
         return P.geometric_interpolator_1d(1025).T.tocsr(), P.poisson_1d_fd(1024)[0]
     if name == "ragged_sq":                      # one row far beyond the capacity limit
@@ -308,6 +314,32 @@ def test_spgemm_matches_scipy_bit_exact(name):
     C2 = plan.numeric(ops.DeviceCSR.from_scipy(A2, DEV, canonical=False), dB).to_scipy()
     w2 = sp.csr_matrix(A2 @ B)
     assert abs(C2 - w2).max() == 0.0
+    # that second run recorded the product map (default "lazy"); later runs replay it without
+    # sorting and must give the same bits for new values of A and of B, with and without `out`
+    if A.nnz and B.nnz:
+        assert plan.recorded_bytes() > 0
+    rng = np.random.default_rng(77)
+    out = None
+    for trial in range(3):
+        A3, B3 = A.copy(), B.copy()
+        A3.data = rng.standard_normal(A.nnz)
+        B3.data = rng.standard_normal(B.nnz)
+        dA3, dB3 = ops.DeviceCSR.from_scipy(A3, DEV, canonical=False), ops.DeviceCSR.from_scipy(B3, DEV, canonical=False)
+        out = plan.numeric(dA3, dB3, out=out if trial else None)
+        C3 = out.to_scipy()
+        fresh = ops.SpGEMMPlan(dA3, dB3, record=False).numeric(dA3, dB3).to_scipy()
+        assert np.array_equal(C3.indptr, fresh.indptr) and np.array_equal(C3.indices, fresh.indices)
+        assert np.array_equal(C3.data, fresh.data), (name, trial)
+        assert abs(C3 - sp.csr_matrix(A3 @ B3)).max() == 0.0
+    # record=True records in the very first run; record=False never does
+    eager = ops.SpGEMMPlan(dA, dB, record=True)
+    C4 = eager.numeric(dA, dB).to_scipy()
+    assert np.array_equal(C4.data, C.data) and np.array_equal(C4.indices, C.indices)
+    C5 = eager.numeric(dA, dB).to_scipy()
+    assert np.array_equal(C5.data, C.data) and np.array_equal(C5.indices, C.indices)
+    never = ops.SpGEMMPlan(dA, dB, record=False)
+    never.numeric(dA, dB), never.numeric(dA, dB), never.numeric(dA, dB)
+    assert never.recorded_bytes() == 0
 
 
 def test_spgemm_dense_operands_take_the_long_row_path():

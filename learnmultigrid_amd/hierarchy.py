@@ -58,7 +58,7 @@ class Hierarchy:
     """levels[0] is the fine grid; transfers[l] (n_l x n_{l+1}) prolongates level l+1 -> l."""
 
     def __init__(self, A, transfers, device, coarse_refine=1, verbose=False, ops_mod=None,
-                 use_packed=True, coarse_solver="auto"):
+                 use_packed=True, coarse_solver="auto", spgemm_record="lazy"):
         # `ops_mod` exists for the CPU-only host-logic tests (a test shim stands in for the
         # HIP kernels); the product always runs with learnmultigrid_amd.ops.
         self.ops = ops if ops_mod is None else ops_mod
@@ -80,9 +80,9 @@ class Hierarchy:
                                  % (len(self.levels) - 1, Ph.shape[0], lev.n))
             lev.P = DeviceCSR.from_scipy(Ph, self.device)
             lev.R = lev.P.transpose()
-            lev.plan_RA = ops_.SpGEMMPlan(lev.R, lev.A)
+            lev.plan_RA = ops_.SpGEMMPlan(lev.R, lev.A, spgemm_record)
             lev.RA = lev.plan_RA.numeric(lev.R, lev.A)
-            lev.plan_RAP = ops_.SpGEMMPlan(lev.RA, lev.P)
+            lev.plan_RAP = ops_.SpGEMMPlan(lev.RA, lev.P, spgemm_record)
             Ac = lev.plan_RAP.numeric(lev.RA, lev.P)
             self.levels.append(Level(Ac))
         self.use_packed = bool(use_packed)

@@ -105,7 +105,7 @@ def dense_gemv_blockdiag(M, x, y):
 
 
 class SpGEMMPlan:
-    def __init__(self, A, B):
+    def __init__(self, A, B, record="lazy"):
         self.shape = (A.shape[0], B.shape[1])
 
     def numeric(self, A, B, out=None):

@@ -32,6 +32,16 @@ def numeric():
         lev = H.levels[l]
         lev.plan_RA.numeric(lev.R, lev.A, out=lev.RA)
         lev.plan_RAP.numeric(lev.RA, lev.P, out=H.levels[l + 1].A)
+from learnmultigrid_amd import coarse as C
+def wrap(obj, name, label):
+    f = getattr(obj, name)
+    def g(*aa, **kk):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(*aa, **kk); torch.cuda.synchronize()
+        print("      [%s %.2f ms]" % (label, (time.perf_counter() - t0) * 1e3)); return r
+    setattr(obj, name, g)
+wrap(C.BandedBlockSolver, "factor", "banded factor")
+wrap(C.BandedBlockSolver, "_symbolic", "banded symbolic")
+wrap(C, "dense_inverse", "dense_inverse")
 for _ in range(2):
     T(numeric, "numeric SpGEMM (all levels)")
     T(lambda: [lev.A.repack_values() for lev in H.levels], "repack values")

@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB
 # HBM bytes per launch of the fine-level Jacobi sweep from rocprofv3 PMC passes
 # (2 x FETCH_SIZE [gfx950 counts wide reads at half size] + WRITE_SIZE, KB -> B), keyed by
 # (--size, packed?); see profiles/ for the runs these come from.  None = not measured.
-PMC_TRAFFIC = {(4096, False): 1485261824, (4096, True): 672639665}
+PMC_TRAFFIC = {(4096, "csr"): 1485261824, (4096, "pcsr"): 672639665, (4096, "rpat"): None}
 
 
 def sweep_bytes(n, nnz):
@@ -64,7 +64,8 @@ def parse():
                     help="learned = row-stochastic perturbed L2-type Q per level (cfg#3/#5)")
     ap.add_argument("--rebuild", type=int, default=0, help="time this many numeric Galerkin rebuilds (cfg#5)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-packed", action="store_true", help="plain CSR kernels (no packed twin)")
+    ap.add_argument("--no-packed", action="store_true", help="plain CSR kernels (no lossless twins at all)")
+    ap.add_argument("--no-patterns", action="store_true", help="packed CSR twin only (no row-pattern twin)")
     return ap.parse_args()
 
 
@@ -132,6 +133,8 @@ def main():
         ops.tune_set("sweep_variant", args.variant)
     if args.no_packed:
         ops.set_packed_enabled(False)
+    if args.no_patterns:
+        ops.set_patterns_enabled(False)
 
     m, levels, nu = args.size, args.levels, args.nu
     if args.problem == "poisson":
@@ -225,24 +228,70 @@ def main():
         ev1.record(stream)
         torch.cuda.synchronize()
         t_jac = ev0.elapsed_time(ev1) * 1e-3 / reps
+        # the same sweep through the plain CSR kernel (what a CSR stream can reach), and the
+        # device copy ceiling of this GPU, both from this run
+        t_csr = None
+        if ops._PACKED_ENABLED and (fine_A.patterns is not None or fine_A.packed is not None):
+            ops.set_packed_enabled(False)
+            for _ in range(2):
+                ops.csr_jacobi(fine_A, xa, ba, args.omega, ya)
+            ev0.record(stream)
+            for _ in range(10):
+                ops.csr_jacobi(fine_A, xa, ba, args.omega, ya)
+            ev1.record(stream)
+            torch.cuda.synchronize()
+            t_csr = ev0.elapsed_time(ev1) * 1e-3 / 10
+            ops.set_packed_enabled(True)
+        cp_src = torch.zeros(1 << 27, dtype=torch.float64, device=dev)       # 1 GiB
+        cp_dst = torch.empty_like(cp_src)
+        for _ in range(2):
+            ops.copy(cp_src, cp_dst)
+        ev0.record(stream)
+        for _ in range(10):
+            ops.copy(cp_src, cp_dst)
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        copy_gbps = 2 * cp_src.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3 / 10) / 1e9
+        for _ in range(2):
+            cp_dst.copy_(cp_src)
+        ev0.record(stream)
+        for _ in range(10):
+            cp_dst.copy_(cp_src)                    # the runtime's own device-to-device copy
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        copy_gbps = max(copy_gbps, 2 * cp_src.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3 / 10) / 1e9)
+        del cp_src, cp_dst
     B = sweep_bytes(fine_A.shape[0], fine_A.nnz)
     achieved = B / t_jac / 1e9
-    pk = fine_A.packed if ops._PACKED_ENABLED else None
-    # bytes the launch really has to move: the packed twin (lossless re-encoding of the CSR
-    # arrays) + x once + b + output
-    B_stored = (pk.bytes() if pk is not None else fine_A.bytes()) + 24 * fine_A.shape[0]
+    rp_ = fine_A.patterns if ops._PACKED_ENABLED else None
+    pk = fine_A.packed if (ops._PACKED_ENABLED and rp_ is None) else None
+    kind = "rpat" if rp_ is not None else ("pcsr" if pk is not None else "csr")
+    # bytes the launch really has to move: the lossless twin of the CSR arrays (DESIGN.md
+    # section 3) + x once + b + output
+    twin = rp_ if rp_ is not None else pk
+    B_stored = (twin.bytes() if twin is not None else fine_A.bytes()) + 24 * fine_A.shape[0]
+    if rp_ is not None:
+        kname = "rpat_sweep_kernel<JACOBI> (row patterns: %d distinct rows, %d entries, 1 B/row)" % (rp_.npat, rp_.nent)
+    elif pk is not None:
+        kname = ("pcsr_sweep_kernel<JACOBI> (packed CSR: colmode %d, valmode %d, %d dictionary values)"
+                 % (pk.colmode, pk.valmode, pk.ndict))
+    else:
+        kname = "csr_sweep_kernel<JACOBI>"
     roofline = {"bound": "hbm",
-                "kernel": ("pcsr_sweep_kernel<JACOBI> (packed CSR: colmode %d, valmode %d, %d dictionary values)"
-                           % (pk.colmode, pk.valmode, pk.ndict)) if pk is not None
-                else "csr_sweep_kernel<JACOBI>",
+                "kernel": kname,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": PMC_TRAFFIC.get((args.size, pk is not None)) if (world == 1 and not force_dist
-                                                                            and args.problem == "poisson") else None,
+                "traffic": PMC_TRAFFIC.get((args.size, kind)) if (world == 1 and not force_dist
+                                                                  and args.problem == "poisson") else None,
+                "copy_ceiling_GBps": copy_gbps,
+                "csr_kernel_same_sweep": None if t_csr is None else {
+                    "kernel": "csr_sweep_kernel<JACOBI>", "avg_launch_ms": t_csr * 1e3, "GBps": B / t_csr / 1e9,
+                    "frac_of_peak": B / t_csr / 1e9 / HBM_PEAK_GBS, "frac_of_copy_ceiling": B / t_csr / 1e9 / copy_gbps},
                 "algorithmic_bytes_per_launch": B, "avg_launch_ms": t_jac * 1e3,
                 "rows_per_launch": int(fine_A.shape[0]),
                 "stored_bytes_per_launch": B_stored,
                 "stored_GBps": B_stored / t_jac / 1e9, "stored_frac_of_peak": B_stored / t_jac / 1e9 / HBM_PEAK_GBS,
+                "stored_frac_of_copy_ceiling": B_stored / t_jac / 1e9 / copy_gbps,
                 "note": "achieved = ALGORITHMIC CSR bytes (12 nnz + 4(n+1) + 24 n) / launch time; the kernel "
                         "reads a lossless packed encoding, so HBM traffic (`traffic`, `stored_*`) is lower than "
                         "the algorithmic bytes and `frac` can exceed what a CSR stream could reach"}
@@ -281,7 +330,7 @@ def main():
                       "level_sizes": [int(s) for s in P.level_sizes(m + 1, levels)],
                       "partition": "row blocks of grid lines over %d rank(s)" % world,
                       "sweep_variant": ops.tune_get("sweep_variant"),
-                      "packed_csr": not args.no_packed},
+                      "packed_csr": not args.no_packed, "fine_level_format": kind},
            "setup_s": setup_s, "roofline": roofline}
     out["config"].update(out_extra)
     if rebuild_ms is not None:

@@ -100,6 +100,33 @@ int lmg_pcsr_sweep(int mode, int64_t n, int64_t nnz, int32_t tile_rows, int32_t 
                    const double *d_x, const double *d_b, double *d_out, double alpha, double beta,
                    double *d_partials, double *d_norm2, void *stream);
 
+/* ---- row-pattern ("RPAT") sweeps ---------------------------------------------------
+ * Second lossless twin, for matrices whose rows repeat when written as (length; column - row
+ * index and value bits of every entry, in storage order): assembled grid operators.  Each
+ * distinct row is stored once, every row carries a uint8 pattern id:
+ *   d_pid[n]                 pattern of every row
+ *   d_pat_ptr[npat+1], d_pat_off[nent], d_pat_val[nent]   the patterns (CSR-like; off = col - row)
+ * Limits from lmg_rpat_limits (255 patterns, 1024 entries in total; held in LDS).  Same modes,
+ * argument meaning and bits as lmg_pcsr_sweep; max_len = longest pattern (picks the unrolling).
+ * d_partials needs lmg_partials_count(n) doubles.
+ * Building (learnmultigrid_amd/ops.py RowPatterns.from_csr is the calling sequence):
+ *   lmg_rpat_row_hash   64-bit hash of every row's pattern
+ *   -- distinct hashes with lmg_value_set_insert, ids with lmg_value_encode --
+ *   lmg_rpat_claim      d_rep[p] (pre-set to -1) = some row with pattern id p
+ *   lmg_rpat_verify     compares EVERY row with its pattern entry by entry (and its columns with
+ *                       [0, ncols)); *d_mismatch != 0 means the format must not be used. */
+int lmg_rpat_limits(int32_t *max_patterns, int32_t *max_entries);
+int lmg_rpat_sweep(int mode, int64_t n, const uint8_t *d_pid, int32_t npat, int32_t nent, int32_t max_len,
+                   const int32_t *d_pat_ptr, const int32_t *d_pat_off, const double *d_pat_val,
+                   const double *d_x, const double *d_b, double *d_out, double alpha, double beta,
+                   double *d_partials, double *d_norm2, void *stream);
+int lmg_rpat_row_hash(int64_t n, const int32_t *d_rowptr, const int32_t *d_colidx, const double *d_vals,
+                      uint64_t *d_hash, void *stream);
+int lmg_rpat_claim(int64_t n, const uint8_t *d_pid, int32_t *d_rep, void *stream);
+int lmg_rpat_verify(int64_t n, int64_t ncols, const int32_t *d_rowptr, const int32_t *d_colidx,
+                    const double *d_vals, const uint8_t *d_pid, int32_t npat, const int32_t *d_pat_ptr,
+                    const int32_t *d_pat_off, const double *d_pat_val, int32_t *d_mismatch, void *stream);
+
 /* ---- building the packed twin (setup) ----------------------------------------------
  * One streaming pass each; learnmultigrid_amd/ops.py PackedCSR.from_csr is the calling sequence.
  *   lmg_pcsr_tile_colrange   smallest / largest column of every tile of `tile_rows` rows

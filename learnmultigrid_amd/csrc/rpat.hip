@@ -1,0 +1,402 @@
+// Row-pattern sweeps for gfx950: residual / Jacobi / SpMV on matrices whose rows repeat.
+//
+// An assembled grid operator (the 5-point Poisson matrix of config #4, its 9-point Galerkin
+// coarsenings) consists of a handful of distinct rows when a row is written as
+//     (length; column - row index, value bits of every entry, in storage order).
+// RPAT stores each distinct row once (<= 255 patterns, <= 1024 entries in total, held in LDS)
+// and one uint8 pattern id per row.  It is a lossless re-encoding of the CSR matrix -- built
+// from the CSR arrays by the kernels at the end of this file, every row verified entry by
+// entry against its pattern -- and the sweep walks the same entries in the same order with the
+// same separately rounded products, so the results are bit-identical to sweep.hip / pcsr.hip.
+// What changes is the byte count: 1 B/row of matrix instead of 16 (PCSR) or 64 (CSR) for
+// the 5-point operator, i.e. the sweep moves x, b and out and almost nothing else.
+// Matrices without repeating rows (variable coefficients, learned transfer operators,
+// rectangular transfers) do not qualify and stay on PCSR / CSR.
+//
+// Kernel: persistent 256-thread workgroups, kRpt rows per thread (row = tile start + k*256 + t,
+// so the gathers of a wave stay coalesced), XCD-aware tile ownership like pcsr.hip, pattern
+// table in LDS (lanes of a wave almost always share a pattern: broadcast reads), JU entries of
+// each of the kRpt rows per step => kRpt*JU independent gathers in flight per thread.
+#include "lmg_common.hpp"
+
+namespace {
+
+enum { MODE_RESIDUAL = 0, MODE_JACOBI = 1, MODE_SPMV = 2 };
+
+constexpr int kBlock = 256;
+constexpr int kMaxPat = 256;      // pattern ids are uint8; id 255 is never used by the builder
+constexpr int kMaxEnt = 1024;     // total entries of all patterns (LDS: 12 KB)
+
+struct RArgs {
+    int n;
+    int tiles;
+    int tiles_per_xcd;
+    int npat;
+    int nent;
+    const int *pat_ptr;        // npat + 1
+    const int *pat_off;        // nent: column - row
+    const double *pat_val;     // nent
+    const unsigned char *pid;  // n
+    const double *x;
+    const double *b;
+    double *out;
+    double alpha, beta;
+    double *partial;
+};
+
+template <int MODE, int JU, int kRpt>
+__global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
+{
+    constexpr int kTileRows = kBlock * kRpt;
+    __shared__ int s_ptr[kMaxPat + 1];
+    __shared__ int s_off[kMaxEnt];
+    __shared__ double s_val[kMaxEnt];
+    __shared__ double s_diag[MODE == MODE_JACOBI ? kMaxPat : 1];
+    __shared__ double s_rdiag[MODE == MODE_JACOBI ? kMaxPat : 1];
+    __shared__ double s_red[kBlock / LMG_WAVE];
+
+    const int t = threadIdx.x;
+    const int xcd = (int)(blockIdx.x & 7u), slot = (int)(blockIdx.x >> 3), nslots = (int)(gridDim.x >> 3);
+    const int t_begin = xcd * a.tiles_per_xcd;
+    const int t_end = min(a.tiles, t_begin + a.tiles_per_xcd);
+    if (t_begin + slot >= t_end) return;
+
+    for (int i = t; i <= a.npat; i += kBlock) s_ptr[i] = a.pat_ptr[i];
+    for (int i = t; i < a.nent; i += kBlock) {
+        s_off[i] = a.pat_off[i];
+        s_val[i] = a.pat_val[i];
+    }
+    __syncthreads();
+    if (MODE == MODE_JACOBI) {
+        // diagonal of every pattern: its entries with offset 0, summed in storage order like
+        // the CSR sweep does per row; one division per pattern and workgroup instead of per row
+        for (int p = t; p < a.npat; p += kBlock) {
+            double d = 0.0;
+            for (int j = s_ptr[p]; j < s_ptr[p + 1]; ++j)
+                if (s_off[j] == 0) d += s_val[j];
+            s_diag[p] = d;
+            s_rdiag[p] = d != 0.0 ? 1.0 / d : 0.0;
+        }
+        __syncthreads();
+    }
+
+    // pattern ids and right-hand sides of the NEXT tile are requested while the current one is
+    // being relaxed: otherwise every tile costs two dependent memory round trips (id -> gathers)
+    int npat_[kRpt];
+    double nbv[kRpt];
+#pragma unroll
+    for (int k = 0; k < kRpt; ++k) {
+        const int r = (t_begin + slot) * kTileRows + k * kBlock + t;
+        npat_[k] = r < a.n ? (int)a.pid[r] : 0;
+        nbv[k] = (MODE != MODE_SPMV && r < a.n) ? a.b[r] : 0.0;
+    }
+    for (int tile = t_begin + slot; tile < t_end; tile += nslots) {
+        const int r0 = tile * kTileRows;
+        int row[kRpt], ps[kRpt], len[kRpt], pat[kRpt];
+        double bv[kRpt], acc[kRpt], xi[kRpt];
+        int maxlen = 0;
+#pragma unroll
+        for (int k = 0; k < kRpt; ++k) {
+            row[k] = r0 + k * kBlock + t;
+            pat[k] = npat_[k];
+            bv[k] = nbv[k];
+        }
+        if (tile + nslots < t_end) {
+#pragma unroll
+            for (int k = 0; k < kRpt; ++k) {
+                const int r = (tile + nslots) * kTileRows + k * kBlock + t;
+                npat_[k] = r < a.n ? (int)a.pid[r] : 0;
+                nbv[k] = (MODE != MODE_SPMV && r < a.n) ? a.b[r] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kRpt; ++k) {
+            ps[k] = s_ptr[pat[k]];
+            len[k] = row[k] < a.n ? s_ptr[pat[k] + 1] - ps[k] : 0;
+            maxlen = max(maxlen, len[k]);
+            acc[k] = 0.0;
+            xi[k] = 0.0;
+        }
+        for (int j0 = 0; j0 < maxlen; j0 += JU) {
+            int off[JU][kRpt];
+            double v[JU][kRpt], xv[JU][kRpt];
+#pragma unroll
+            for (int jj = 0; jj < JU; ++jj) {
+#pragma unroll
+                for (int k = 0; k < kRpt; ++k) {
+                    const bool act = j0 + jj < len[k];
+                    const int p = act ? ps[k] + j0 + jj : 0;
+                    off[jj][k] = s_off[p];
+                    v[jj][k] = s_val[p];
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < JU; ++jj) {
+#pragma unroll
+                for (int k = 0; k < kRpt; ++k) {
+                    const bool act = j0 + jj < len[k];
+#if defined(LMG_RPAT_EXP) && LMG_RPAT_EXP == 1      // timing experiment: same instruction count, L1 hits
+                    xv[jj][k] = a.x[act ? row[k] : 0];
+#elif defined(LMG_RPAT_EXP) && LMG_RPAT_EXP == 2    // timing experiment: one gather per row
+                    xv[jj][k] = (jj == 0 && j0 == 0) ? a.x[act ? row[k] : 0] : (double)off[jj][k];
+#else
+                    xv[jj][k] = a.x[act ? row[k] + off[jj][k] : 0];
+#endif
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < JU; ++jj) {
+#pragma unroll
+                for (int k = 0; k < kRpt; ++k) {
+                    const bool act = j0 + jj < len[k];
+                    const double s2 = acc[k] + v[jj][k] * xv[jj][k];
+                    acc[k] = act ? s2 : acc[k];
+                    if (MODE == MODE_JACOBI) xi[k] = (act && off[jj][k] == 0) ? xv[jj][k] : xi[k];
+                }
+            }
+        }
+        double local = 0.0;
+#pragma unroll
+        for (int k = 0; k < kRpt; ++k) {
+            if (row[k] < a.n) {
+                if (MODE == MODE_RESIDUAL) {
+                    const double r = bv[k] - acc[k];
+                    if (a.out) a.out[row[k]] = r;
+                    local += r * r;
+                } else if (MODE == MODE_JACOBI) {
+                    const double r = bv[k] - acc[k];
+                    if (s_diag[pat[k]] != 0.0) a.out[row[k]] = xi[k] + a.alpha * (s_rdiag[pat[k]] * r);
+                    else a.out[row[k]] = a.x[row[k]];
+                } else {
+                    double s = acc[k];
+                    if (a.alpha != 1.0) s = a.alpha * s;
+                    if (a.beta == 0.0) a.out[row[k]] = s;
+                    else if (a.beta == 1.0) a.out[row[k]] = a.out[row[k]] + s;
+                    else a.out[row[k]] = a.beta * a.out[row[k]] + s;
+                }
+            }
+        }
+        if (MODE == MODE_RESIDUAL && a.partial != nullptr) {
+            __syncthreads();
+            const double tot = lmg_block_sum<kBlock>(local, s_red);
+            if (t == 0) a.partial[tile] = tot;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024) rpat_reduce_partials_kernel(const double *partial, int64_t count, double *out)
+{
+    __shared__ double s_red[1024 / LMG_WAVE];
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    int64_t i = threadIdx.x;
+    for (; i + 3 * 1024 < count; i += 4 * 1024) {
+        v0 += partial[i];
+        v1 += partial[i + 1024];
+        v2 += partial[i + 2048];
+        v3 += partial[i + 3072];
+    }
+    for (; i < count; i += 1024) v0 += partial[i];
+    const double tot = lmg_block_sum<1024>((v0 + v1) + (v2 + v3), s_red);
+    if (threadIdx.x == 0) out[0] = tot;
+}
+
+int g_rpat_variant = 0;      // 0 = pick from the longest pattern; 1.. = forced (tuning)
+
+template <int MODE, int JU, int kRpt>
+int launch_one(RArgs a, hipStream_t st)
+{
+    a.tiles = (a.n + kBlock * kRpt - 1) / (kBlock * kRpt);
+    a.tiles_per_xcd = (a.tiles + 7) / 8;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rpat_sweep_kernel<MODE, JU, kRpt>, kBlock, 0) !=
+            hipSuccess || per_cu < 1)
+        per_cu = 4;
+    if (per_cu > 8) per_cu = 8;
+    int64_t grid = 256 * (int64_t)per_cu;
+    if (grid > (int64_t)a.tiles_per_xcd * 8) grid = (int64_t)a.tiles_per_xcd * 8;
+    hipLaunchKernelGGL((rpat_sweep_kernel<MODE, JU, kRpt>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
+    LMG_CHECK_LAUNCH();
+    return a.tiles;
+}
+
+template <int MODE>
+int launch(RArgs a, int maxlen, hipStream_t st)
+{
+    int v = g_rpat_variant;
+    if (v == 0) v = maxlen <= 5 ? 1 : (maxlen <= 9 ? 4 : 6);
+    switch (v) {
+    case 1: return launch_one<MODE, 5, 1>(a, st);
+    case 2: return launch_one<MODE, 5, 2>(a, st);
+    case 3: return launch_one<MODE, 1, 4>(a, st);
+    case 4: return launch_one<MODE, 3, 2>(a, st);
+    case 5: return launch_one<MODE, 9, 1>(a, st);
+    case 6: return launch_one<MODE, 5, 4>(a, st);
+    case 7: return launch_one<MODE, 3, 4>(a, st);
+    case 8: return launch_one<MODE, 2, 4>(a, st);
+    default: return LMG_ERR_ARG;
+    }
+}
+
+// ---- building the format (setup) -------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+
+// 64-bit hash of (length; column - row, value bits ...) of every row; never the all-ones value
+__global__ void __launch_bounds__(256) row_pattern_hash_kernel(int64_t n, const int *__restrict__ rowptr,
+                                                               const int *__restrict__ colidx,
+                                                               const unsigned long long *__restrict__ vbits,
+                                                               unsigned long long *__restrict__ hash)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int s = rowptr[i], e = rowptr[i + 1];
+    unsigned long long h = mix64(0x9E3779B97F4A7C15ull + (unsigned long long)(e - s));
+    for (int j = s; j < e; ++j) {
+        h = mix64(h ^ (unsigned long long)(unsigned)(colidx[j] - (int)i));
+        h = mix64(h ^ vbits[j]);
+    }
+    if (h == ~0ull) h = 0;
+    hash[i] = h;
+}
+
+// one representative row per pattern: whoever gets there first (every row is verified later)
+__global__ void __launch_bounds__(256) pattern_claim_kernel(int64_t n, const unsigned char *__restrict__ pid, int *rep)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int p = pid[i];
+    if (__atomic_load_n(&rep[p], __ATOMIC_RELAXED) < 0) atomicCAS(&rep[p], -1, (int)i);
+}
+
+// every row against its pattern, entry by entry (hash collisions must not pass)
+__global__ void __launch_bounds__(256) pattern_verify_kernel(int64_t n, int64_t ncols, const int *__restrict__ rowptr,
+                                                             const int *__restrict__ colidx,
+                                                             const unsigned long long *__restrict__ vbits,
+                                                             const unsigned char *__restrict__ pid, int npat,
+                                                             const int *__restrict__ pat_ptr,
+                                                             const int *__restrict__ pat_off,
+                                                             const unsigned long long *__restrict__ pat_vbits,
+                                                             int *mismatch)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int p = pid[i];
+    bool ok = p < npat;
+    if (ok) {
+        const int s = rowptr[i], e = rowptr[i + 1], ps = pat_ptr[p];
+        ok = (e - s) == pat_ptr[p + 1] - ps;
+        for (int j = 0; ok && j < e - s; ++j) {
+            const int c = colidx[s + j];
+            ok = (c - (int)i == pat_off[ps + j]) && (vbits[s + j] == pat_vbits[ps + j]) && c >= 0 && c < ncols;
+        }
+    }
+    if (!ok) *mismatch = 1;
+}
+
+}  // namespace
+
+int lmg_rpat_tune_set(int v)
+{
+    if (v < 0 || v > 8) return LMG_ERR_ARG;
+    g_rpat_variant = v;
+    return LMG_OK;
+}
+int lmg_rpat_tune_get(void) { return g_rpat_variant; }
+
+extern "C" {
+
+int lmg_rpat_limits(int32_t *max_patterns, int32_t *max_entries)
+{
+    if (max_patterns) *max_patterns = kMaxPat - 1;
+    if (max_entries) *max_entries = kMaxEnt;
+    return LMG_OK;
+}
+
+int lmg_rpat_sweep(int mode, int64_t n, const uint8_t *pid, int32_t npat, int32_t nent, int32_t max_len,
+                   const int32_t *pat_ptr, const int32_t *pat_off, const double *pat_val, const double *x,
+                   const double *b, double *out, double alpha, double beta, double *partials, double *norm2,
+                   void *stream)
+{
+    if (n < 0 || n >= INT32_MAX || npat < 1 || npat >= kMaxPat || nent < 0 || nent > kMaxEnt) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    if (!pid || !pat_ptr || !x || (nent > 0 && (!pat_off || !pat_val))) return LMG_ERR_ARG;
+    if (mode == MODE_SPMV) {
+        if (!out || x == out) return LMG_ERR_ARG;
+    } else if (mode == MODE_JACOBI) {
+        if (!b || !out || x == out) return LMG_ERR_ARG;
+    } else if (mode == MODE_RESIDUAL) {
+        if (!b || (partials == nullptr) != (norm2 == nullptr) || (!out && !partials)) return LMG_ERR_ARG;
+    } else {
+        return LMG_ERR_ARG;
+    }
+    RArgs a;
+    a.n = (int)n;
+    a.tiles = a.tiles_per_xcd = 0;
+    a.npat = npat;
+    a.nent = nent;
+    a.pat_ptr = pat_ptr;
+    a.pat_off = pat_off;
+    a.pat_val = pat_val;
+    a.pid = pid;
+    a.x = x;
+    a.b = b;
+    a.out = out;
+    a.alpha = alpha;
+    a.beta = beta;
+    a.partial = (mode == MODE_RESIDUAL) ? partials : nullptr;
+    hipStream_t st = lmg_stream(stream);
+    int tiles;
+    if (mode == MODE_RESIDUAL) tiles = launch<MODE_RESIDUAL>(a, max_len, st);
+    else if (mode == MODE_JACOBI) tiles = launch<MODE_JACOBI>(a, max_len, st);
+    else tiles = launch<MODE_SPMV>(a, max_len, st);
+    if (tiles < 0) return tiles;
+    if (mode == MODE_RESIDUAL && partials) {
+        hipLaunchKernelGGL(rpat_reduce_partials_kernel, dim3(1), dim3(1024), 0, st, partials, (int64_t)tiles, norm2);
+        LMG_CHECK_LAUNCH();
+    }
+    return LMG_OK;
+}
+
+int lmg_rpat_row_hash(int64_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, uint64_t *hash,
+                      void *stream)
+{
+    if (n < 0) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    if (!rowptr || !hash) return LMG_ERR_ARG;
+    row_pattern_hash_kernel<<<(unsigned)((n + 255) / 256), 256, 0, lmg_stream(stream)>>>(
+        n, rowptr, colidx, reinterpret_cast<const unsigned long long *>(vals),
+        reinterpret_cast<unsigned long long *>(hash));
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_rpat_claim(int64_t n, const uint8_t *pid, int32_t *rep, void *stream)
+{
+    if (n < 0) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    if (!pid || !rep) return LMG_ERR_ARG;
+    pattern_claim_kernel<<<(unsigned)((n + 255) / 256), 256, 0, lmg_stream(stream)>>>(n, pid, rep);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_rpat_verify(int64_t n, int64_t ncols, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                    const uint8_t *pid, int32_t npat, const int32_t *pat_ptr, const int32_t *pat_off,
+                    const double *pat_val, int32_t *mismatch, void *stream)
+{
+    if (n < 0 || npat < 1) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    if (!rowptr || !pid || !pat_ptr || !mismatch) return LMG_ERR_ARG;
+    pattern_verify_kernel<<<(unsigned)((n + 255) / 256), 256, 0, lmg_stream(stream)>>>(
+        n, ncols, rowptr, colidx, reinterpret_cast<const unsigned long long *>(vals), pid, npat, pat_ptr, pat_off,
+        reinterpret_cast<const unsigned long long *>(pat_val), mismatch);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+}  // extern "C"

@@ -7,6 +7,8 @@ int lmg_sweep_tune_set(int rpt);
 int lmg_sweep_tune_get(void);
 int lmg_pcsr_tune_set(int ju);
 int lmg_pcsr_tune_get(void);
+int lmg_rpat_tune_set(int v);
+int lmg_rpat_tune_get(void);
 
 namespace {
 
@@ -231,6 +233,7 @@ int lmg_tune_set(const char *key, int value)
     if (!key) return LMG_ERR_ARG;
     if (strcmp(key, "sweep_variant") == 0) return lmg_sweep_tune_set(value);
     if (strcmp(key, "pcsr_ju") == 0) return lmg_pcsr_tune_set(value);
+    if (strcmp(key, "rpat_variant") == 0) return lmg_rpat_tune_set(value);
     return LMG_ERR_ARG;
 }
 
@@ -239,6 +242,7 @@ int lmg_tune_get(const char *key)
     if (!key) return LMG_ERR_ARG;
     if (strcmp(key, "sweep_variant") == 0) return lmg_sweep_tune_get();
     if (strcmp(key, "pcsr_ju") == 0) return lmg_pcsr_tune_get();
+    if (strcmp(key, "rpat_variant") == 0) return lmg_rpat_tune_get();
     return LMG_ERR_ARG;
 }
 

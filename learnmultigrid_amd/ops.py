@@ -37,7 +37,7 @@ def _vec_ok(*ts):
 class DeviceCSR:
     """CSR matrix resident in HBM: int32 rowptr[n+1], int32 colidx[nnz], fp64 vals[nnz]."""
 
-    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz", "packed")
+    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz", "packed", "patterns")
 
     def __init__(self, rowptr, colidx, vals, shape):
         if rowptr.dtype != I32 or colidx.dtype != I32 or vals.dtype != F64:
@@ -48,21 +48,37 @@ class DeviceCSR:
         self.shape = (int(shape[0]), int(shape[1]))
         self.nnz = int(vals.numel())
         self.packed = None           # PackedCSR twin used by the sweeps once pack() was called
+        self.patterns = None         # RowPatterns twin (matrices with repeating rows), preferred
 
-    def pack(self):
-        """Build (once) the packed twin the sweep kernels prefer; keeps the CSR arrays."""
-        if self.packed is None and self.vals.is_cuda:
+    def pack(self, patterns=None):
+        """Build (once) the lossless twin the sweep kernels prefer; keeps the CSR arrays.
+        Row patterns (RowPatterns) when the rows repeat -- assembled grid operators --, else the
+        packed CSR (PackedCSR).  patterns=False forces the packed CSR, None = module default."""
+        if not self.vals.is_cuda:
+            return None
+        if patterns is None:
+            patterns = _PATTERNS_ENABLED
+        if patterns and self.patterns is None and self.packed is None:
+            self.patterns = RowPatterns.from_csr(self)
+        if patterns and self.patterns is not None:
+            return self.patterns
+        if self.packed is None:
             self.packed = PackedCSR.from_csr(self)
         return self.packed
 
     def invalidate_packed(self):
         self.packed = None
+        self.patterns = None
 
     def repack_values(self):
-        """After the values changed in place: refresh the packed twin (cheaply if possible)."""
+        """After the values changed in place: refresh the twins (cheaply if possible)."""
+        if self.patterns is not None:
+            self.patterns = RowPatterns.from_csr(self)
+            if self.patterns is None:
+                self.pack()
         if self.packed is not None and not self.packed.update_values(self):
             self.packed = None
-            self.pack()
+            self.pack(patterns=False)
 
     @classmethod
     def from_scipy(cls, A, device, canonical=True):
@@ -131,15 +147,16 @@ class PackedCSR:
         return torch.zeros(((nbytes + 15) // 16) * 16 + 16, dtype=torch.uint8, device=device)
 
     @classmethod
-    def _distinct_values(cls, vals):
+    def _distinct_values(cls, vals, limit=None):
         """Sorted (as signed 64-bit patterns) distinct values of `vals`, or None when there are
-        more than _VSET_LIMIT of them.  Hash-set kernel + a sort of the few survivors instead of
-        sorting all nnz values."""
+        more than `limit` (default _VSET_LIMIT) of them.  Hash-set kernel + a sort of the few
+        survivors instead of sorting all nnz values."""
         L = _lib.lib()
         dev = vals.device
+        limit = cls._VSET_LIMIT if limit is None else int(limit)
         table = torch.full((cls._VSET_SLOTS,), -1, dtype=torch.int64, device=dev)
         state = torch.zeros(4, dtype=I32, device=dev)
-        check(L.lmg_value_set_insert(vals.numel(), _p(vals), _p(table), cls._VSET_SLOTS, cls._VSET_LIMIT,
+        check(L.lmg_value_set_insert(vals.numel(), _p(vals), _p(table), cls._VSET_SLOTS, limit,
                                      _p(state), _s()), "lmg_value_set_insert")
         st = state.cpu()
         if int(st[1]):
@@ -147,7 +164,7 @@ class PackedCSR:
         keys = table[table != -1]
         if int(st[2]):
             keys = torch.cat([keys, torch.full((1,), -1, dtype=torch.int64, device=dev)])
-        if keys.numel() > cls._VSET_LIMIT:
+        if keys.numel() > limit:
             return None
         return torch.sort(keys).values.contiguous()
 
@@ -246,14 +263,90 @@ class PackedCSR:
         return True
 
 
+class RowPatterns:
+    """Lossless row-pattern twin of a DeviceCSR for lmg_rpat_sweep (see include/lmg.h): every
+    distinct row -- (length; column - row and value bits of each entry, in storage order) -- is
+    stored once, each row carries a uint8 pattern id.  Only matrices with at most 255 distinct
+    rows and 1024 pattern entries qualify (assembled constant-coefficient grid operators and
+    their Galerkin coarsenings); from_csr returns None for everything else."""
+
+    __slots__ = ("n", "nnz", "shape", "pid", "npat", "nent", "max_len", "pat_ptr", "pat_off", "pat_val", "bytes_")
+
+    @classmethod
+    def from_csr(cls, A):
+        n, nnz = A.shape[0], A.nnz
+        if n == 0 or nnz == 0 or not A.vals.is_cuda:
+            return None
+        L = _lib.lib()
+        dev = A.vals.device
+        mp, me = ctypes.c_int32(0), ctypes.c_int32(0)
+        check(L.lmg_rpat_limits(ctypes.addressof(mp), ctypes.addressof(me)), "lmg_rpat_limits")
+        max_pat, max_ent = int(mp.value), int(me.value)
+        hashes = torch.empty(n, dtype=torch.int64, device=dev)
+        check(L.lmg_rpat_row_hash(n, _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(hashes), _s()), "lmg_rpat_row_hash")
+        uniq = PackedCSR._distinct_values(hashes.view(F64), limit=max_pat)
+        if uniq is None:
+            return None
+        npat = int(uniq.numel())
+        pid = torch.empty(n, dtype=torch.uint8, device=dev)
+        PackedCSR._encode_values(hashes.view(F64), uniq, 1, pid)
+        del hashes
+        rep = torch.full((256,), -1, dtype=I32, device=dev)
+        check(L.lmg_rpat_claim(n, _p(pid), _p(rep), _s()), "lmg_rpat_claim")
+        rep = rep[:npat].long()
+        if int(rep.min()) < 0:
+            return None
+        starts, ends = A.rowptr[rep].cpu().numpy().astype(np.int64), A.rowptr[rep + 1].cpu().numpy().astype(np.int64)
+        lens = ends - starts
+        nent = int(lens.sum())
+        if nent > max_ent:
+            return None
+        idx = np.concatenate([np.arange(s_, e_) for s_, e_ in zip(starts, ends)]) if nent else np.zeros(0, np.int64)
+        d_idx = torch.from_numpy(idx).to(dev)
+        rows_of = torch.from_numpy(np.repeat(rep.cpu().numpy(), lens)).to(dev)
+        self = cls()
+        self.n, self.nnz, self.shape = n, nnz, A.shape
+        self.pid = pid
+        self.npat, self.nent = npat, nent
+        self.max_len = int(lens.max())
+        ptr = np.zeros(npat + 1, dtype=np.int32)
+        np.cumsum(lens, out=ptr[1:])
+        self.pat_ptr = torch.from_numpy(ptr).to(dev)
+        self.pat_off = (A.colidx[d_idx].long() - rows_of).to(I32).contiguous() if nent else torch.zeros(1, dtype=I32, device=dev)
+        self.pat_val = A.vals[d_idx].contiguous() if nent else torch.zeros(1, dtype=F64, device=dev)
+        mismatch = torch.zeros(1, dtype=I32, device=dev)
+        check(L.lmg_rpat_verify(n, A.shape[1], _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(pid), npat, _p(self.pat_ptr),
+                                _p(self.pat_off), _p(self.pat_val), _p(mismatch), _s()), "lmg_rpat_verify")
+        if int(mismatch):
+            return None                                # a hash collision: not worth a second try
+        self.bytes_ = n + 4 * (npat + 1) + 12 * nent
+        return self
+
+    def bytes(self):
+        return int(self.bytes_)
+
+
 _PACKED_ENABLED = True
+_PATTERNS_ENABLED = True
 
 
 def set_packed_enabled(flag):
-    """Route csr_jacobi / csr_residual_norm2 / csr_spmv through the packed twin when one
-    exists (default) or always through the plain CSR kernels (A/B and parity tests)."""
+    """Route csr_jacobi / csr_residual_norm2 / csr_spmv through the lossless twins when they
+    exist (default) or always through the plain CSR kernels (A/B and parity tests)."""
     global _PACKED_ENABLED
     _PACKED_ENABLED = bool(flag)
+
+
+def set_patterns_enabled(flag):
+    """Whether pack() may pick the row-pattern twin (default) or always builds the packed CSR."""
+    global _PATTERNS_ENABLED
+    _PATTERNS_ENABLED = bool(flag)
+
+
+def _rpat(mode, R, x, b, out, alpha, beta, partials, norm2):
+    return _lib.lib().lmg_rpat_sweep(mode, R.n, _p(R.pid), R.npat, R.nent, R.max_len, _p(R.pat_ptr), _p(R.pat_off),
+                                     _p(R.pat_val), _p(x), _p(b), _p(out), float(alpha), float(beta),
+                                     _p(partials), _p(norm2), _s())
 
 
 def _pcsr(mode, P, x, b, out, alpha, beta, partials, norm2):
@@ -280,6 +373,9 @@ def tune_get(key):
 def csr_residual_norm2(A, x, b, r, partials, norm2):
     """r = b - A x (r may be None), norm2[0] = sum r_i^2 (partials/norm2 may both be None)."""
     _vec_ok(x, b, r, partials, norm2)
+    if _PACKED_ENABLED and A.patterns is not None:
+        check(_rpat(0, A.patterns, x, b, r, 0.0, 0.0, partials, norm2), "lmg_rpat_sweep(residual)")
+        return
     if _PACKED_ENABLED and A.packed is not None:
         rc = _pcsr(0, A.packed, x, b, r, 0.0, 0.0, partials, norm2)
         if rc != -4:                                   # LMG_ERR_CAPACITY: tile too large for LDS
@@ -292,6 +388,9 @@ def csr_residual_norm2(A, x, b, r, partials, norm2):
 
 def csr_jacobi(A, x_in, b, omega, x_out):
     _vec_ok(x_in, b, x_out)
+    if _PACKED_ENABLED and A.patterns is not None:
+        check(_rpat(1, A.patterns, x_in, b, x_out, omega, 0.0, None, None), "lmg_rpat_sweep(jacobi)")
+        return
     if _PACKED_ENABLED and A.packed is not None:
         rc = _pcsr(1, A.packed, x_in, b, x_out, omega, 0.0, None, None)
         if rc != -4:
@@ -305,6 +404,9 @@ def csr_spmv(A, x, y, alpha=1.0, beta=0.0):
     _vec_ok(x, y)
     if x.numel() != A.shape[1] or y.numel() != A.shape[0]:
         raise ValueError("spmv shape mismatch: A %s, x %d, y %d" % (A.shape, x.numel(), y.numel()))
+    if _PACKED_ENABLED and A.patterns is not None:
+        check(_rpat(2, A.patterns, x, None, y, alpha, beta, None, None), "lmg_rpat_sweep(spmv)")
+        return
     if _PACKED_ENABLED and A.packed is not None:
         rc = _pcsr(2, A.packed, x, None, y, alpha, beta, None, None)
         if rc != -4:

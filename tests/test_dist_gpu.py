@@ -73,7 +73,10 @@ def _gpu_worker(rank, world, port, out_dir):
         hier = P.geometric_hierarchy_2d(m + 1, levels)
         D = DistributedVCycle.from_problem(A, hier, "cuda:0", grid_side=m + 1, replicate_below=20000)
         assert D.host_staged and D.n_dist == 2
-        assert all(M.packed is not None and M.packed.colmode == 0 for d in D.dl for M in (d.A, d.R, d.P))
+        # local operators run on their lossless twins: row patterns for the square grid operators
+        # (ghost rows are one more pattern), 16-bit packed columns for the transfers
+        assert all(d.A.patterns is not None for d in D.dl)
+        assert all(M.packed is not None and M.packed.colmode == 0 for d in D.dl for M in (d.R, d.P))
         D.set_rhs(rhs)
         with torch.cuda.stream(D.stream):
             norms = [D.residual_norm()]

@@ -449,8 +449,8 @@ def test_packed_sweeps_bit_exact(name):
     rng = np.random.default_rng(21)
     x, b, y0 = rng.standard_normal(m), rng.standard_normal(n), rng.standard_normal(n)
     dA = ops.DeviceCSR.from_scipy(A, DEV)
-    Pk = dA.pack()
-    assert Pk is not None
+    Pk = dA.pack(patterns=False)
+    assert Pk is not None and dA.patterns is None
     want_modes = {"val8": 0, "val16": 1, "val64": 2}
     for key, vm in want_modes.items():
         if name.startswith(key):
@@ -502,7 +502,7 @@ def test_packing_is_refused_for_rows_longer_than_255_and_preserves_signed_zero()
     # -0.0 and +0.0 are different dictionary entries (bitwise dictionary)
     M = sp.csr_matrix((np.array([0.0, -0.0, 1.0, 2.0]), np.array([0, 1, 0, 1]), np.array([0, 2, 4])), shape=(2, 2))
     dM = ops.DeviceCSR(dev(M.indptr.astype(np.int32)), dev(M.indices.astype(np.int32)), dev(M.data), (2, 2))
-    Pk = dM.pack()
+    Pk = dM.pack(patterns=False)
     assert Pk.ndict == 4
     x = np.array([-1.0, 1.0])
     y = torch.empty(2, dtype=torch.float64, device=DEV)
@@ -536,7 +536,7 @@ def _numpy_pack(A, T):
 def test_packed_format_matches_its_numpy_restatement(name):
     A = packed_case(name)
     dA = ops.DeviceCSR.from_scipy(A, DEV)
-    Pk = dA.pack()
+    Pk = dA.pack(patterns=False)
     base, cmin, cmax, rel, uniq, idx = _numpy_pack(A, Pk.tile_rows)
     nnz = A.nnz
     assert np.array_equal(Pk.tile_base.cpu().numpy(), base)
@@ -604,7 +604,7 @@ def test_distinct_value_set_limits_and_special_bit_patterns():
 def test_update_values_reencodes_or_asks_for_a_repack():
     A = packed_case("val8_col16_poisson2d_513")
     dA = ops.DeviceCSR.from_scipy(A, DEV)
-    Pk = dA.pack()
+    Pk = dA.pack(patterns=False)
     assert Pk.valmode == 0
     x = np.random.default_rng(3).standard_normal(A.shape[0])
     B = A.copy()
@@ -656,3 +656,150 @@ def test_inverse_diagonal_kernel():
         want[i] = 1.0 / d if d != 0.0 else 0.0
     assert np.array_equal(got, want)
     assert want[3] == 0.0 and want[77] == 0.0 and want[200] == 0.0
+
+
+# ---- row-pattern twin (rpat.hip) ---------------------------------------------------------------
+def _numpy_row_patterns(A):
+    """Distinct rows of A written as (length; column - row, value bits ...), with numpy."""
+    keys = {}
+    ids = np.empty(A.shape[0], dtype=np.int64)
+    for i in range(A.shape[0]):
+        s, e = A.indptr[i], A.indptr[i + 1]
+        k = (tuple((A.indices[s:e] - i).tolist()), A.data[s:e].tobytes())
+        ids[i] = keys.setdefault(k, len(keys))
+    return keys, ids
+
+
+@functools.lru_cache(maxsize=None)
+def rpat_case(name):
+    if name == "poisson2d_129":
+        return K.as_csr(P.poisson_2d_structured(128)[0])
+    if name == "poisson1d":
+        return K.as_csr(P.poisson_1d_fd(3000)[0])
+    if name == "galerkin_9pt":
+        return packed_case("galerkin_9pt")
+    if name == "galerkin_l2_rounded":                 # 25-entry rows, few patterns
+        return packed_case("val8_longrows_l2_galerkin")
+    if name == "with_empty_and_diagless_rows":
+        A = P.poisson_2d_structured(40)[0].tolil()
+        A[5, :] = 0.0                                 # empty row
+        A[77, 77] = 0.0                               # row without a diagonal entry
+        A = sp.csr_matrix(A)
+        A.eliminate_zeros()
+        return K.as_csr(A)
+    if name == "duplicate_diagonal":                  # non-canonical: two diagonal entries per row
+        n = 500
+        rp = np.arange(0, 3 * n + 1, 3, dtype=np.int32)
+        ci = np.stack([np.arange(n), np.arange(n), (np.arange(n) + 1) % n], 1).astype(np.int32).ravel()
+        va = np.tile(np.array([2.0, 0.5, -1.0]), n)
+        return sp.csr_matrix((va, ci, rp), shape=(n, n))
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["poisson2d_129", "poisson1d", "galerkin_9pt", "galerkin_l2_rounded",
+                                  "with_empty_and_diagless_rows", "duplicate_diagonal"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+def test_row_pattern_sweeps_bit_exact(name, variant):
+    A = rpat_case(name)
+    n = A.shape[0]
+    keys, ids = _numpy_row_patterns(A)
+    if name == "duplicate_diagonal":
+        dA = ops.DeviceCSR(dev(A.indptr.astype(np.int32)), dev(A.indices.astype(np.int32)), dev(A.data), A.shape)
+    else:
+        dA = ops.DeviceCSR.from_scipy(A, DEV)
+    R = dA.pack()
+    assert isinstance(R, ops.RowPatterns) and dA.packed is None
+    assert R.npat == len(keys) and R.nent == sum(len(k[0]) for k in keys) and R.max_len == max(len(k[0]) for k in keys)
+    # same partition of the rows into patterns, and every pattern reproduces its rows
+    pid = R.pid.cpu().numpy()
+    assert len(set(zip(pid.tolist(), ids.tolist()))) == len(keys)
+    ptr, off, val = R.pat_ptr.cpu().numpy(), R.pat_off.cpu().numpy(), R.pat_val.cpu().numpy()
+    for i in (0, 1, n // 3, n // 2, n - 2, n - 1):
+        s, e = A.indptr[i], A.indptr[i + 1]
+        p = pid[i]
+        assert np.array_equal(off[ptr[p]:ptr[p + 1]], A.indices[s:e] - i)
+        assert np.array_equal(val[ptr[p]:ptr[p + 1]].view(np.int64), A.data[s:e].view(np.int64))
+    assert R.bytes() < 0.2 * dA.bytes()
+    rng = np.random.default_rng(23)
+    x, b, y0 = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
+    # oracle kernels on the RAW arrays (K.spmv & co. would merge the duplicate entries first)
+    rp_, ci_, va_ = A.indptr.astype(np.int32), A.indices.astype(np.int32), np.ascontiguousarray(A.data)
+
+    class Raw:
+        @staticmethod
+        def spmv(_, x_, y_, al, be):
+            o = y_.copy()
+            K.lib().orc_csr_spmv(n, rp_, ci_, va_, x_, o, al, be)
+            return o
+
+        @staticmethod
+        def residual(_, x_, b_):
+            o = np.empty(n)
+            return o, K.lib().orc_csr_residual(n, rp_, ci_, va_, x_, b_, o)
+
+        @staticmethod
+        def jacobi(_, x_, b_, om):
+            o = np.empty(n)
+            K.lib().orc_csr_jacobi(n, rp_, ci_, va_, x_, b_, om, o)
+            return o
+    Ac = A
+    try:
+        ops.tune_set("rpat_variant", variant)
+        for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (-0.5, 2.0)):
+            y = dev(y0.copy())
+            ops.csr_spmv(dA, dev(x), y, alpha, beta)
+            assert np.array_equal(y.cpu().numpy(), Raw.spmv(Ac, x, y0, alpha, beta)), (name, alpha, beta)
+        r = torch.empty(n, dtype=torch.float64, device=DEV)
+        part = torch.empty(ops.partials_count(n), dtype=torch.float64, device=DEV)
+        n2 = torch.zeros(1, dtype=torch.float64, device=DEV)
+        ops.csr_residual_norm2(dA, dev(x), dev(b), r, part, n2)
+        wr, wn2 = Raw.residual(Ac, x, b)
+        assert np.array_equal(r.cpu().numpy(), wr)
+        assert abs(n2.item() - wn2) <= 1e-13 * wn2
+        n2b = torch.zeros(1, dtype=torch.float64, device=DEV)
+        ops.csr_residual_norm2(dA, dev(x), dev(b), None, part, n2b)
+        assert n2b.item() == n2.item()
+        for omega in (1.0, 0.8):
+            out = torch.empty(n, dtype=torch.float64, device=DEV)
+            ops.csr_jacobi(dA, dev(x), dev(b), omega, out)
+            assert np.array_equal(out.cpu().numpy(), Raw.jacobi(Ac, x, b, omega)), (name, omega)
+        # ... and it really is another kernel than the CSR one
+        ops.set_packed_enabled(False)
+        out2 = torch.empty(n, dtype=torch.float64, device=DEV)
+        ops.csr_jacobi(dA, dev(x), dev(b), 0.8, out2)
+        assert torch.equal(out, out2)
+    finally:
+        ops.set_packed_enabled(True)
+        ops.tune_set("rpat_variant", 0)
+
+
+def test_row_patterns_are_refused_when_rows_do_not_repeat():
+    for name in ("val64_col16_jittered", "val8_col16_prolong", "val16_col16_ragged"):
+        dA = ops.DeviceCSR.from_scipy(packed_case(name), DEV)
+        Pk = dA.pack()
+        assert dA.patterns is None and isinstance(Pk, ops.PackedCSR), name
+    # too many pattern entries in total (more than 1024), although few rows
+    rng = np.random.default_rng(2)
+    A = sp.csr_matrix(rng.standard_normal((40, 40)))
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    dA.pack()
+    assert dA.patterns is None and dA.packed is not None
+    # values changed in place: the pattern twin is rebuilt, or dropped when rows stop repeating
+    A = rpat_case("poisson2d_129")
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    assert isinstance(dA.pack(), ops.RowPatterns)
+    x = rng.standard_normal(A.shape[0])
+    y = torch.empty(A.shape[0], dtype=torch.float64, device=DEV)
+    B = A.copy()
+    B.data = B.data * 3.0
+    dA.vals.copy_(dev(B.data))
+    dA.repack_values()
+    assert dA.patterns is not None
+    ops.csr_spmv(dA, dev(x), y)
+    assert np.array_equal(y.cpu().numpy(), K.spmv(B, x, np.zeros_like(x), 1.0, 0.0))
+    B.data = rng.standard_normal(B.nnz)
+    dA.vals.copy_(dev(B.data))
+    dA.repack_values()
+    assert dA.patterns is None and dA.packed is not None
+    ops.csr_spmv(dA, dev(x), y)
+    assert np.array_equal(y.cpu().numpy(), K.spmv(B, x, np.zeros_like(x), 1.0, 0.0))

@@ -91,9 +91,12 @@ __global__ __launch_bounds__(kPackBlock) void value_set_insert_kernel(int64_t co
     __syncthreads();
     volatile int *vstate = state;
     const int64_t stride = (int64_t)gridDim.x * kPackBlock;
+    unsigned long long last = kEmpty;
     for (int64_t i = (int64_t)blockIdx.x * kPackBlock + threadIdx.x; i < count; i += stride) {
         const unsigned long long key = bits[i];
         if (key == kEmpty) { vstate[2] = 1; continue; }
+        if (key == last) continue;       // already inserted by this thread
+        last = key;
         const uint64_t h0 = mix64(key);
         const int f = (int)(h0 >> 40) & (kFilterSlots - 1);
         if (s_seen[f] == key) continue;

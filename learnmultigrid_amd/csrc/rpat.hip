@@ -80,37 +80,30 @@ __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
         __syncthreads();
     }
 
-    // pattern ids and right-hand sides of the NEXT tile are requested while the current one is
-    // being relaxed: otherwise every tile costs two dependent memory round trips (id -> gathers)
-    int npat_[kRpt];
-    double nbv[kRpt];
+    // Pattern ids and right-hand sides travel through registers two tiles ahead, in two register
+    // sets (A, B) used alternately.  The loop body is straight-line on purpose: the loads of set A
+    // are issued before the gathers of the tile that uses set B, so waiting for those gathers
+    // (vmcnt counts in order) already guarantees set A without any wait at the top of the loop.
+    // With a one-tile prefetch the loop top needed s_waitcnt vmcnt(0), which also waited for the
+    // previous tile's STORE: two serialized memory round trips per tile instead of one.
+    auto load_tile = [&](int tile, int (&pat)[kRpt], double (&bv)[kRpt]) {
+        const int tl = tile < t_end ? tile : t_end - 1;          // past the end: harmless re-read
 #pragma unroll
-    for (int k = 0; k < kRpt; ++k) {
-        const int r = (t_begin + slot) * kTileRows + k * kBlock + t;
-        npat_[k] = r < a.n ? (int)a.pid[r] : 0;
-        nbv[k] = (MODE != MODE_SPMV && r < a.n) ? a.b[r] : 0.0;
-    }
-    for (int tile = t_begin + slot; tile < t_end; tile += nslots) {
+        for (int k = 0; k < kRpt; ++k) {
+            const int r = tl * kTileRows + k * kBlock + t;
+            pat[k] = r < a.n ? (int)a.pid[r] : 0;
+            bv[k] = (MODE != MODE_SPMV && r < a.n) ? a.b[r] : 0.0;
+        }
+    };
+    auto process = [&](int tile, const int (&pat)[kRpt], const double (&bv)[kRpt]) {
         const int r0 = tile * kTileRows;
-        int row[kRpt], ps[kRpt], len[kRpt], pat[kRpt];
-        double bv[kRpt], acc[kRpt], xi[kRpt];
+        double local = 0.0;
+        int row[kRpt], ps[kRpt], len[kRpt];
+        double acc[kRpt], xi[kRpt];
         int maxlen = 0;
 #pragma unroll
         for (int k = 0; k < kRpt; ++k) {
             row[k] = r0 + k * kBlock + t;
-            pat[k] = npat_[k];
-            bv[k] = nbv[k];
-        }
-        if (tile + nslots < t_end) {
-#pragma unroll
-            for (int k = 0; k < kRpt; ++k) {
-                const int r = (tile + nslots) * kTileRows + k * kBlock + t;
-                npat_[k] = r < a.n ? (int)a.pid[r] : 0;
-                nbv[k] = (MODE != MODE_SPMV && r < a.n) ? a.b[r] : 0.0;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < kRpt; ++k) {
             ps[k] = s_ptr[pat[k]];
             len[k] = row[k] < a.n ? s_ptr[pat[k] + 1] - ps[k] : 0;
             maxlen = max(maxlen, len[k]);
@@ -135,13 +128,7 @@ __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
 #pragma unroll
                 for (int k = 0; k < kRpt; ++k) {
                     const bool act = j0 + jj < len[k];
-#if defined(LMG_RPAT_EXP) && LMG_RPAT_EXP == 1      // timing experiment: same instruction count, L1 hits
-                    xv[jj][k] = a.x[act ? row[k] : 0];
-#elif defined(LMG_RPAT_EXP) && LMG_RPAT_EXP == 2    // timing experiment: one gather per row
-                    xv[jj][k] = (jj == 0 && j0 == 0) ? a.x[act ? row[k] : 0] : (double)off[jj][k];
-#else
                     xv[jj][k] = a.x[act ? row[k] + off[jj][k] : 0];
-#endif
                 }
             }
 #pragma unroll
@@ -155,7 +142,10 @@ __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
                 }
             }
         }
-        double local = 0.0;
+        // Free on the usual path (the last gather was just waited for with vmcnt(0)); it tells the
+        // compiler's wait-count tracking that the other register set is complete on EVERY path,
+        // including the one that skips the gather loop (all rows of the tile empty).
+        __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
         for (int k = 0; k < kRpt; ++k) {
             if (row[k] < a.n) {
@@ -181,7 +171,21 @@ __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
             const double tot = lmg_block_sum<kBlock>(local, s_red);
             if (t == 0) a.partial[tile] = tot;
         }
+    };
+    int patA[kRpt], patB[kRpt];
+    double bA[kRpt], bB[kRpt];
+    int tile = t_begin + slot;
+    load_tile(tile, patA, bA);
+    load_tile(tile + nslots, patB, bB);
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the loop is entered with both sets complete
+    while (tile + nslots < t_end) {
+        process(tile, patA, bA);
+        load_tile(tile + 2 * nslots, patA, bA);
+        process(tile + nslots, patB, bB);
+        load_tile(tile + 3 * nslots, patB, bB);
+        tile += 2 * nslots;
     }
+    if (tile < t_end) process(tile, patA, bA);
 }
 
 __global__ void __launch_bounds__(1024) rpat_reduce_partials_kernel(const double *partial, int64_t count, double *out)
@@ -200,7 +204,7 @@ __global__ void __launch_bounds__(1024) rpat_reduce_partials_kernel(const double
     if (threadIdx.x == 0) out[0] = tot;
 }
 
-int g_rpat_variant = 0;      // 0 = pick from the longest pattern; 1.. = forced (tuning)
+int g_rpat_variant = 0;      // 0 = pick from the longest pattern; 1..4 = forced (tuning)
 
 template <int MODE, int JU, int kRpt>
 int launch_one(RArgs a, hipStream_t st)
@@ -223,16 +227,13 @@ template <int MODE>
 int launch(RArgs a, int maxlen, hipStream_t st)
 {
     int v = g_rpat_variant;
-    if (v == 0) v = maxlen <= 5 ? 1 : (maxlen <= 9 ? 4 : 6);
+    // measured on MI355X (tools/time_rpat.py): all geometries are within 10 % of each other
+    if (v == 0) v = maxlen <= 5 ? 2 : 4;
     switch (v) {
     case 1: return launch_one<MODE, 5, 1>(a, st);
     case 2: return launch_one<MODE, 5, 2>(a, st);
     case 3: return launch_one<MODE, 1, 4>(a, st);
     case 4: return launch_one<MODE, 3, 2>(a, st);
-    case 5: return launch_one<MODE, 9, 1>(a, st);
-    case 6: return launch_one<MODE, 5, 4>(a, st);
-    case 7: return launch_one<MODE, 3, 4>(a, st);
-    case 8: return launch_one<MODE, 2, 4>(a, st);
     default: return LMG_ERR_ARG;
     }
 }
@@ -268,8 +269,10 @@ __global__ void __launch_bounds__(256) row_pattern_hash_kernel(int64_t n, const 
 __global__ void __launch_bounds__(256) pattern_claim_kernel(int64_t n, const unsigned char *__restrict__ pid, int *rep)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int p = pid[i];
+    const int p = i < n ? (int)pid[i] : -1;
+    // neighbouring rows mostly share their pattern: only the first lane of every run asks
+    const int prev = __shfl_up(p, 1, LMG_WAVE);
+    if (p < 0 || ((threadIdx.x & (LMG_WAVE - 1)) != 0 && prev == p)) return;
     if (__atomic_load_n(&rep[p], __ATOMIC_RELAXED) < 0) atomicCAS(&rep[p], -1, (int)i);
 }
 
@@ -302,7 +305,7 @@ __global__ void __launch_bounds__(256) pattern_verify_kernel(int64_t n, int64_t 
 
 int lmg_rpat_tune_set(int v)
 {
-    if (v < 0 || v > 8) return LMG_ERR_ARG;
+    if (v < 0 || v > 4) return LMG_ERR_ARG;
     g_rpat_variant = v;
     return LMG_OK;
 }

@@ -698,7 +698,7 @@ def rpat_case(name):
 
 @pytest.mark.parametrize("name", ["poisson2d_129", "poisson1d", "galerkin_9pt", "galerkin_l2_rounded",
                                   "with_empty_and_diagless_rows", "duplicate_diagonal"])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_row_pattern_sweeps_bit_exact(name, variant):
     A = rpat_case(name)
     n = A.shape[0]

@@ -5,7 +5,7 @@ import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, scipy.sparse as sp
 from learnmultigrid_amd import ops, problems as P
-ap = argparse.ArgumentParser(); ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,8"); ap.add_argument("--size", type=int, default=4096)
+ap = argparse.ArgumentParser(); ap.add_argument("--variants", default="0,1,2,3,4"); ap.add_argument("--size", type=int, default=4096)
 a = ap.parse_args()
 cases = []
 A, _ = P.poisson_2d_structured(a.size); cases.append(("5pt %d^2" % (a.size + 1), A))

@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(256) gs_rows_kernel(const int *rowptr, const i
 // loads of set s+1 issued by other waves of the SAME workgroup (same CU): a
 // workgroup-scope release/acquire fence around the barrier is sufficient for that.
 constexpr int kSingleBlock = 1024;
+int g_gs_single_max = 2 * kSingleBlock;     // widest set the one-workgroup executor takes (tunable)
 __global__ void __launch_bounds__(kSingleBlock) gs_single_wg_kernel(
     const int *rowptr, const int *colidx, const double *vals, double *x, const double *b,
     const int *set_rows, const int *set_ptr, int64_t nsets, int sweeps)
@@ -153,6 +154,14 @@ void transpose_pattern(int64_t n, const int32_t *Ap, const int32_t *Aj, std::vec
 
 }  // namespace
 
+int lmg_gs_tune_set(int v)
+{
+    if (v < 1) return LMG_ERR_ARG;
+    g_gs_single_max = v;
+    return LMG_OK;
+}
+int lmg_gs_tune_get(void) { return g_gs_single_max; }
+
 extern "C" {
 
 int lmg_csr_gs_rows(const int32_t *rp, const int32_t *ci, const double *va, double *x, const double *b,
@@ -199,7 +208,7 @@ int lmg_csr_gs_schedule(const int32_t *rp, const int32_t *ci, const double *va, 
         LMG_CHECK_LAUNCH();
         return LMG_OK;
     }
-    if (max_set <= 2 * kSingleBlock) {
+    if (max_set <= g_gs_single_max) {
         hipLaunchKernelGGL(gs_single_wg_kernel, dim3(1), dim3(kSingleBlock), 0, st, rp, ci, va, x, b,
                            d_set_rows, d_set_ptr, nsets, sweeps);
         LMG_CHECK_LAUNCH();

@@ -97,10 +97,28 @@ def cpu_baseline(A, hier, rhs, args):
         dt = time.perf_counter() - t0
         sweeps = (2 * args.nu + 1) * args.cpu_cycles
         what = "%d full V(%d,%d) cycles, %d levels" % (args.cpu_cycles, args.nu, args.nu, len(hier) + 1)
-    return {"value": n * sweeps / dt, "unit": "DoF*sweeps/s", "cores": 1, "kind": "port",
-            "sample": "%s of the same %d-DoF problem in %.1f s (setup %.1f s not counted), "
-                      "oracle/ single thread; host has %d logical CPUs"
-                      % (what, n, dt, t_setup, os.cpu_count() or 0)}
+    out = {"value": n * sweeps / dt, "unit": "DoF*sweeps/s", "cores": 1, "kind": "port",
+           "sample": "%s of the same %d-DoF problem in %.1f s (setup %.1f s not counted), "
+                     "oracle/ single thread; host has %d logical CPUs"
+                     % (what, n, dt, t_setup, os.cpu_count() or 0)}
+    if args.mode == "vcycle":
+        # for honesty: ONE cycle the way the reference really runs it -- forward
+        # Gauss-Seidel whatever the smoother argument says, transfer lookup, R A P and the SuperLU
+        # factorisation all inside the cycle (Multigrid.py:77-124) -- at cfg#2 size
+        from learnmultigrid_amd import problems as P
+        m2 = 512
+        A2, rhs2 = P.poisson_2d_structured(m2)
+        ref = V.RefMultigrid(A2, rhs2.reshape(-1, 1), hierarchy=P.geometric_hierarchy_2d(m2 + 1, 3))
+        u0 = np.zeros((A2.shape[0], 1))
+        t0 = time.perf_counter()
+        ref.v_cycle(ref.matrix, u0, ref.rhs, "Jacobi", args.nu, 1e-10, 3, first_call=True)
+        t_ref = time.perf_counter() - t0
+        out["reference_style_cycle_cfg2"] = {
+            "ms_per_cycle": t_ref * 1e3, "DoF_sweeps_per_s": A2.shape[0] * (2 * args.nu + 1) / t_ref,
+            "what": "one un-hoisted as-shipped V(%d,%d) cycle, 513^2 DoF, 3 levels: forward GS smoothing, "
+                    "Galerkin products and SuperLU spsolve inside the cycle (oracle/vcycle_ref.py RefMultigrid)"
+                    % (args.nu, args.nu)}
+    return out
 
 
 def main():

@@ -180,7 +180,8 @@ def main():
     if world > 1 or force_dist:
         from learnmultigrid_amd.dist import DistributedVCycle
         t0 = time.perf_counter()
-        D = DistributedVCycle.from_problem(A, hier, dev, grid_side=m + 1)
+        D = DistributedVCycle.from_problem(A, hier, dev, grid_side=m + 1,
+                                           halo_depth=int(os.environ.get("LMG_HALO_DEPTH", nu + 3)))
         setup_s = time.perf_counter() - t0
         D.set_rhs(rhs)
         stream = D.stream
@@ -324,7 +325,8 @@ def main():
     cyc_bytes, coarse_bytes = H.cycle_bytes(nu) if args.mode == "vcycle" and world == 1 else (None, None)
     if world > 1 or force_dist:
         out_extra = {"distributed_levels": D.n_dist, "rows_per_rank_fine": n_loc_fine,
-                     "halo_values_fine": D.dl[0].n_lo + D.dl[0].n_hi}
+                     "halo_values_fine": D.dl[0].n_lo + D.dl[0].n_hi, "halo_depth": D.halo_depth,
+                     "halo_exchanges_per_cycle": D.n_exchanges / max(1, args.steps + args.warmup)}
     else:
         out_extra = {}
 

@@ -15,8 +15,19 @@ point-to-point xGMI links):
     A_l, R_l and P_{l-1} reference), so every level-l vector has the layout
     [owned rows | ghosts sorted by global index] and one exchange plan.
   * One halo exchange = a pack kernel (lmg_gather) + one grouped batch of
-    isend / irecv (<= 2 neighbours, 32.8 KB per neighbour on the fine level of cfg#4).
-    Messages are latency-bound, not xGMI-bandwidth-bound.
+    isend / irecv (<= 2 neighbours).  Messages are latency-bound, not xGMI-bandwidth-bound,
+    so the cycle is organised to need FEW of them: the ghost set of a level reaches
+    `halo_depth` (default 6 = nu + 1 + the two hops the 9-point restriction of a 5-point
+    operator reads, for nu = 3) matrix hops beyond the owned block and the local
+    operator A_l carries the real rows of all but the outermost ghost layer.  After one
+    exchange of x every sweep on the whole local block is exact one layer less deep than the
+    previous one, so nu sweeps, the residual on the owned rows AND on the first ghost layer
+    (which the restriction reads) need no further message: 3 exchanges per level and cycle
+    (x before pre-smoothing -- b on the coarse levels, whose iterate starts from zero --, the
+    coarse correction before prolongation, x before post-smoothing) instead of 2 nu + 3.
+    The redundant work is halo_depth grid lines per neighbour (197 KB messages on the fine
+    level of cfg#4).  Levels whose restriction reads further than the halo allows, and cycles
+    with more sweeps, fall back to one exchange per use on that level.
   * Levels with fewer than `replicate_below` rows (default 2 M: below that a halo
     exchange costs more than computing the whole level redundantly) are NOT distributed: the restricted
     residual is all-gathered once per cycle and every rank runs the rest of the cycle
@@ -56,6 +67,21 @@ def _rows(M, lo, hi):
     return (rp - s).to(I32), M.colidx[s:e], M.vals[s:e]
 
 
+def _gather_rows(M, rows):
+    """Entries of the given rows (int64 tensor) of a CSR in tensors: (counts, colidx, vals),
+    rows in the given order, entries in storage order."""
+    if rows.numel() == 0:
+        return (torch.zeros(0, dtype=torch.long, device=M.vals.device), M.colidx[:0], M.vals[:0])
+    start = M.rowptr[rows].long()
+    cnt = M.rowptr[rows + 1].long() - start
+    tot = int(cnt.sum())
+    if tot == 0:
+        return cnt, M.colidx[:0], M.vals[:0]
+    first = torch.cumsum(cnt, 0) - cnt                       # position of every row's first entry
+    idx = torch.repeat_interleave(start - first, cnt) + torch.arange(tot, device=M.vals.device)
+    return cnt, M.colidx[idx], M.vals[idx]
+
+
 class _DLevel:
     """One distributed level on this rank.  Vector layout (length n_tot):
         [ghosts below lo | owned rows lo..hi | ghosts above hi]      (all in global order)
@@ -80,7 +106,7 @@ class _DLevel:
 
 class DistributedVCycle:
     def __init__(self, full, device, ops_mod=None, grid_side=None, replicate_below=2_000_000,
-                 group=None):
+                 group=None, halo_depth=6):
         """full: a replicated hierarchy (learnmultigrid_amd.hierarchy.Hierarchy or anything
         with the same .levels[l].A/.P/.R, .coarse_solve(), .cycle())."""
         if ops_mod is None:
@@ -95,6 +121,10 @@ class DistributedVCycle:
         # "gloo" cannot move device tensors point to point: when it drives GPU ranks (tests that put
         # several ranks on one GPU, or a node without RCCL) messages are staged through the host
         self.host_staged = self.device.type == "cuda" and dist.get_backend(group) == "gloo"
+        # ghost layers per level (matrix hops); cycles with nu + 2 <= halo_depth exchange 3 times
+        # per level, others before every sweep.  1 = the classic one-layer halo.
+        self.halo_depth = max(1, int(halo_depth))
+        self.n_exchanges = 0                      # halo exchanges issued so far (tests, bench)
         nlev = len(full.levels)
         sizes = [lev.n for lev in full.levels]
         # ---- which levels are distributed -------------------------------------------------
@@ -134,17 +164,55 @@ class DistributedVCycle:
             clo, chi = self.bounds[l + 1][self.rank], self.bounds[l + 1][self.rank + 1]
             lev = full.levels[l]
             raw.append({"A": _rows(lev.A, lo, hi), "P": _rows(lev.P, lo, hi), "R": _rows(lev.R, clo, chi)})
-        ghosts = []
+        ghosts, real_ghosts, r_need = [], [], []
         for l in range(self.n_dist):
             lo, hi = self.bounds[l][self.rank], self.bounds[l][self.rank + 1]
-            cols = [raw[l]["A"][1], raw[l]["R"][1]]
+            A_l = full.levels[l].A
+
+            def outside(c, known):
+                c = c.long()
+                c = torch.unique(c[(c < lo) | (c >= hi)])
+                if known.numel():
+                    pos = torch.searchsorted(known, c).clamp(max=known.numel() - 1)
+                    c = c[known[pos] != c]
+                return c
+
+            # layer k = rows reached from the owned block in k hops through A_l; the rows of all
+            # layers but the last are kept as REAL rows of the local operator
+            known = torch.zeros(0, dtype=torch.long, device=A_l.vals.device)
+            frontier = outside(raw[l]["A"][1], known)
+            real = known
+            layers = []
+            for k in range(self.halo_depth):
+                layers.append(frontier)
+                known = torch.unique(torch.cat([known, frontier]))
+                if k + 1 == self.halo_depth or frontier.numel() == 0:
+                    break
+                real = known
+                frontier = outside(_gather_rows(A_l, frontier)[1], known)
+            # deepest ghost layer the restriction reads (a residual is exact on layer k only if x
+            # is exact on layer k + 1); columns that A does not reach within halo_depth hops at all
+            # rule the few-exchanges scheme out on this level
+            rc = outside(raw[l]["R"][1], known[:0])
+            need = 0
+            if rc.numel():
+                lay = torch.full((rc.numel(),), 1 << 20, dtype=torch.long, device=rc.device)
+                for k, fr in enumerate(layers, 1):
+                    if fr.numel():
+                        pos = torch.searchsorted(fr, rc).clamp(max=fr.numel() - 1)
+                        lay = torch.where(fr[pos] == rc, torch.full_like(lay, k), lay)
+                need = int(lay.max())
+            r_need.append(need)
+            extra = [raw[l]["R"][1]]
             if l > 0:
-                cols.append(raw[l - 1]["P"][1])
-            allc = torch.cat(cols).long()
-            out = allc[(allc < lo) | (allc >= hi)]
-            ghosts.append(torch.unique(out))           # sorted
+                extra.append(raw[l - 1]["P"][1])
+            known = torch.unique(torch.cat([known, outside(torch.cat(extra), known)]))
+            ghosts.append(known)                       # sorted
+            real_ghosts.append(real)
         gathered = [None] * self.world
-        dist.all_gather_object(gathered, [g.cpu().numpy() for g in ghosts], group=group)
+        dist.all_gather_object(gathered, [g.cpu().numpy() for g in ghosts] + [r_need], group=group)
+        # every rank must take the same branch of the cycle (the exchanges are collective)
+        self.r_need = [max(g[-1][l] for g in gathered) for l in range(self.n_dist)]
         self.dl = []
         for l in range(self.n_dist):
             d = _DLevel()
@@ -187,8 +255,32 @@ class DistributedVCycle:
         for l in range(self.n_dist):
             d = self.dl[l]
             rp, ci, va = raw[l]["A"]
-            d.A = DeviceCSR(d.embed_rows(rp), d.to_local(ci).to(I32).contiguous(), va.contiguous(),
-                            (d.n_tot, d.n_tot))
+            A_l = full.levels[l].A
+            rg = real_ghosts[l]
+            parts_rp, parts_ci, parts_va = [], [], []
+            for gset in (d.ghost_lo, None, d.ghost_hi):
+                if gset is None:
+                    parts_rp.append((rp[1:] - rp[:-1]).long())
+                    parts_ci.append(ci)
+                    parts_va.append(va)
+                    continue
+                if gset.numel() and rg.numel():
+                    pos = torch.searchsorted(rg, gset).clamp(max=rg.numel() - 1)
+                    is_real = rg[pos] == gset
+                else:
+                    is_real = torch.zeros(gset.numel(), dtype=torch.bool, device=gset.device)
+                cnt, gci, gva = _gather_rows(A_l, gset[is_real])
+                full_cnt = torch.zeros(gset.numel(), dtype=torch.long, device=gset.device)
+                full_cnt[is_real] = cnt
+                parts_rp.append(full_cnt)
+                parts_ci.append(gci)
+                parts_va.append(gva)
+            counts = torch.cat(parts_rp)
+            rp_loc = torch.zeros(d.n_tot + 1, dtype=I32, device=va.device)
+            rp_loc[1:] = torch.cumsum(counts, 0).to(I32)
+            d.A = DeviceCSR(rp_loc, d.to_local(torch.cat(parts_ci)).to(I32).contiguous(),
+                            torch.cat(parts_va).contiguous(), (d.n_tot, d.n_tot))
+            d.rows_global = torch.cat([d.ghost_lo, torch.arange(d.lo, d.hi, device=va.device), d.ghost_hi])
             d.dinv = self.ops.csr_inverse_diagonal(d.A)
             rp, ci, va = raw[l]["R"]                      # rows: level l+1, columns: level l
             rp_p, ci_p, va_p = raw[l]["P"]                # rows: level l,   columns: level l+1
@@ -249,6 +341,7 @@ class DistributedVCycle:
         """Fill the ghost segment of `vec` (layout of level d) from the owning ranks."""
         if not d.recv and not d.send:
             return
+        self.n_exchanges += 1
         p2p, landing = [], []
         for q, idx, buf in d.send:
             if isinstance(idx, tuple):                      # contiguous run of owned rows: no pack kernel
@@ -273,8 +366,7 @@ class DistributedVCycle:
     def set_rhs(self, rhs):
         d = self.dl[0]
         full = torch.from_numpy(np.ascontiguousarray(np.asarray(rhs, dtype=np.float64).reshape(-1)))
-        d.b.zero_()                                   # ghost rows are empty rows: their rhs is 0
-        d.b[d.own].copy_(full[d.lo:d.hi])
+        d.b.copy_(full[d.rows_global.cpu()])          # ghost rows carry real matrix rows: their rhs too
 
     def set_x(self, x):
         d = self.dl[0]
@@ -289,17 +381,25 @@ class DistributedVCycle:
         return np.concatenate(parts)
 
     # ---- the cycle ---------------------------------------------------------------------------------------
-    def _smooth(self, d, steps, omega, x_is_zero=False):
+    def _smooth(self, d, steps, omega, x_is_zero=False, deep=False):
+        """`steps` Jacobi sweeps on the whole local block.  deep: the ghosts of x (of b when the
+        iterate starts from zero) are exchanged ONCE; sweep k is then exact up to ghost layer
+        halo_depth - k, which is all the next sweep needs.  Otherwise one exchange per sweep."""
         o = self.ops
         if x_is_zero and steps > 0:
-            # first sweep from zeros: x = omega * (D^-1 b), no halo needed
+            if deep:
+                self.exchange(d, d.b)
+            # first sweep from zeros: x = omega * (D^-1 b), no halo of x needed
             o.vmul(omega, d.dinv, d.b, d.tmp)
             d.x, d.tmp = d.tmp, d.x
             steps -= 1
         elif x_is_zero:
             o.zero(d.x)
-        for _ in range(steps):
+        elif deep:
             self.exchange(d, d.x)
+        for _ in range(steps):
+            if not deep:
+                self.exchange(d, d.x)
             o.csr_jacobi(d.A, d.x, d.b, omega, d.tmp)
             d.x, d.tmp = d.tmp, d.x
 
@@ -309,10 +409,15 @@ class DistributedVCycle:
                              "(lexicographic Gauss-Seidel is sequential across ranks)")
         o = self.ops
         d = self.dl[l]
-        self._smooth(d, steps, omega, x_is_zero)
-        self.exchange(d, d.x)
+        # nu sweeps + the residual on the ghost layers the restriction reads consume nu + 1 + r_need
+        # layers of one exchange; otherwise (deeper cycles, wide transfers) exchange before every use
+        deep = steps >= 1 and steps + 1 + max(1, self.r_need[l]) <= self.halo_depth
+        self._smooth(d, steps, omega, x_is_zero, deep)
+        if not deep:
+            self.exchange(d, d.x)
         o.csr_residual_norm2(d.A, d.x, d.b, d.r, None, None)
-        self.exchange(d, d.r)
+        if not deep:
+            self.exchange(d, d.r)
         if l + 1 < self.n_dist:
             nxt = self.dl[l + 1]
             o.csr_spmv(d.R, d.r, nxt.b, 1.0, 0.0)
@@ -331,7 +436,7 @@ class DistributedVCycle:
             o.gather(self.ag_index, self.ag_recv, fl.b)
             self._replicated_tail(smoother, steps, omega, l + 1)
             o.csr_spmv(d.P, fl.x, d.x, 1.0, 1.0)
-        self._smooth(d, steps, omega)
+        self._smooth(d, steps, omega, False, deep)
 
     def _replicated_tail(self, smoother, steps, omega, l):
         """The part of the cycle below the distributed levels: purely local work on the
@@ -363,7 +468,9 @@ class DistributedVCycle:
         """||b - A x||_2 over all ranks: local fused sum of squares + all-reduce of 8 bytes."""
         d = self.dl[0]
         self.exchange(d, d.x)
-        self.ops.csr_residual_norm2(d.A, d.x, d.b, d.r, self.partials, self.norm2)
+        self.ops.csr_residual_norm2(d.A, d.x, d.b, d.r, None, None)
+        r_own = d.r[d.own]                              # ghost rows are real rows: count the owned ones only
+        self.ops.dot(r_own, r_own, self.partials, self.norm2)
         if self.host_staged:
             h = self.norm2.cpu()
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)

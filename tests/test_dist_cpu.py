@@ -27,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, m, levels, replicate_below, out_dir):
+def _worker(rank, world, port, m, levels, replicate_below, steps, halo_depth, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -41,11 +41,14 @@ def _worker(rank, world, port, m, levels, replicate_below, out_dir):
         A, rhs = P.poisson_2d_structured(m)
         hier = P.geometric_hierarchy_2d(m + 1, levels)
         D = DistributedVCycle.from_problem(A, hier, "cpu", ops_mod=shim, grid_side=m + 1,
-                                           replicate_below=replicate_below)
+                                           replicate_below=replicate_below, halo_depth=halo_depth)
         D.set_rhs(rhs)
         norms = [D.residual_norm()]
+        per_cycle = []
         for _ in range(3):
-            D.cycle("Jacobi", 2, 0.8)
+            before = D.n_exchanges
+            D.cycle("Jacobi", steps, 0.8)
+            per_cycle.append(D.n_exchanges - before)
             norms.append(D.residual_norm())
         x = D.gather_solution()
         # single-process run of the same arithmetic
@@ -53,14 +56,14 @@ def _worker(rank, world, port, m, levels, replicate_below, out_dir):
         H.levels[0].b.copy_(torch.from_numpy(rhs.ravel().copy()))
         ref_norms = [H.residual_norm()]
         for _ in range(3):
-            H.cycle("Jacobi", 2, 0.8)
+            H.cycle("Jacobi", steps, 0.8)
             ref_norms.append(H.residual_norm())
         xr = H.levels[0].x.numpy()
         side = m + 1
         info = {"bit_identical": bool(np.array_equal(x, xr)),
                 "norm_rel": float(max(abs(a - b) / b for a, b in zip(norms, ref_norms))),
                 "contracting": bool(norms[-1] < 0.05 * norms[0]),
-                "n_dist": D.n_dist,
+                "n_dist": D.n_dist, "exchanges_per_cycle": per_cycle, "r_need": D.r_need,
                 "cuts_on_lines": all(c % sd == 0 for l, sd in enumerate(P.level_sizes(side, D.n_dist + 1))
                                      for c in D.bounds[l]),
                 "ghosts": [d.n_lo + d.n_hi for d in D.dl],
@@ -72,10 +75,16 @@ def _worker(rank, world, port, m, levels, replicate_below, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,m,levels,replicate_below", [(2, 32, 4, 200), (2, 48, 3, 1), (3, 40, 4, 300)])
-def test_distributed_vcycle_matches_single_process(tmp_path, world, m, levels, replicate_below):
+@pytest.mark.parametrize("world,m,levels,replicate_below,steps,halo_depth",
+                         [(2, 32, 4, 200, 2, 6), (2, 48, 3, 1, 2, 6), (3, 40, 4, 300, 2, 6),
+                          (2, 48, 3, 1, 3, 6),          # nu + 3 = halo depth: still three exchanges per level
+                          (2, 48, 3, 1, 3, 5),          # fine level one layer short (its restriction reads two hops away)
+                          (2, 48, 3, 1, 4, 5),          # deeper cycle than the halo: exchange before every sweep
+                          (3, 40, 4, 300, 2, 1)])       # classic one-layer halo (empty ghost rows)
+def test_distributed_vcycle_matches_single_process(tmp_path, world, m, levels, replicate_below, steps, halo_depth):
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, m, levels, replicate_below, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, m, levels, replicate_below, steps, halo_depth, str(tmp_path)),
+             nprocs=world, join=True)
     for r in range(world):
         info = eval(str(np.load(os.path.join(str(tmp_path), "info_%d.npy" % r))[0]))
         assert info["bit_identical"], info
@@ -83,9 +92,22 @@ def test_distributed_vcycle_matches_single_process(tmp_path, world, m, levels, r
         assert info["contracting"], info
         assert info["cuts_on_lines"], info
         assert info["n_dist"] >= 1
-        # interior ranks talk to two neighbours, edge ranks to one
+        # number of halo exchanges of one cycle: 3 per distributed level with the deep halo (the
+        # deepest one has no distributed level below it to fetch a correction from: 2), against
+        # 2 nu + 2 (+1) with one exchange per use
+        nd = info["n_dist"]
+        deep = [steps + 1 + max(1, rn) <= halo_depth for rn in info["r_need"]]
+        if all(deep):
+            assert all(c == 3 * nd - 1 for c in info["exchanges_per_cycle"]), info
+        elif not any(deep):
+            assert all(c >= (2 * steps + 1) * nd for c in info["exchanges_per_cycle"]), info
+        # the 9-point restriction of a 5-point operator reads residuals two matrix hops away
+        assert info["r_need"][0] == (2 if halo_depth >= 2 else 1 << 20), info
+        # interior ranks talk to two neighbours, edge ranks to one (thin coarse blocks of these tiny
+        # test grids may reach one rank further with the deep halo)
         want = [q for q in (r - 1, r + 1) if 0 <= q < world]
-        assert all(nb == want for nb in info["neighbours"]), info
+        assert all(set(want) <= set(nb) for nb in info["neighbours"]), info
+        assert info["neighbours"][0] == want, info
 
 
 def test_block_bounds():

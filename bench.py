@@ -184,6 +184,7 @@ def main():
                                            halo_depth=int(os.environ.get("LMG_HALO_DEPTH", nu + 3)))
         setup_s = time.perf_counter() - t0
         D.set_rhs(rhs)
+        D.use_tail_graph = not args.no_graph
         stream = D.stream
         with torch.cuda.stream(stream):
             step = D.make_step("Jacobi", nu, args.omega, graph=not args.no_graph)

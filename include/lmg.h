@@ -171,6 +171,16 @@ int lmg_csr_gs_schedule(const int32_t *d_rowptr, const int32_t *d_colidx, const 
                         double *d_x, const double *d_b, const int32_t *d_set_rows,
                         const int32_t *d_set_ptr, const int32_t *h_set_ptr, int64_t nsets,
                         int64_t max_set, int sweeps, void *stream);
+/* The one-workgroup executor of lmg_csr_gs_schedule on a copy of the PATTERN in schedule order
+ * (for schedules of a few thousand rows per set at most: grids up to ~1025^2): d_ell_row[k] the
+ * k-th scheduled row, d_ell_start[k] / d_ell_len[k] its entry range in the CSR arrays,
+ * d_ell_cols[j * total_rows + k] its j-th column (j < ell_k in {3, 5, 7, 9, 16} >= the longest
+ * row; padding entries hold the row itself).  Values are read from d_vals, so the copy stays
+ * valid across coefficient changes.  Same results as lmg_csr_gs_schedule, bit for bit. */
+int lmg_csr_gs_schedule_ell(const double *d_vals, double *d_x, const double *d_b, const int32_t *d_ell_row,
+                            const int32_t *d_ell_start, const int32_t *d_ell_len, const int32_t *d_ell_cols,
+                            int32_t ell_k, int64_t total_rows, const int32_t *d_set_ptr, int64_t nsets,
+                            int sweeps, void *stream);
 
 /* HOST helpers (host pointers, run on the CPU at setup time).
  * level[i] = 1 + max(level[j] : j < i adjacent to i in A + A^T), 0 if none: rows of equal

@@ -62,6 +62,73 @@ __global__ void __launch_bounds__(kSingleBlock) gs_single_wg_kernel(
     }
 }
 
+// The same executor on a copy of the PATTERN in schedule order (ELL, column-major: entry j of
+// scheduled row k at ell_cols[j * total + k]).  gs_single_wg_kernel pays four dependent memory
+// round trips per set (row id -> row pointer -> column -> x); here the row id, its entry range
+// and all its columns are one level of coalesced loads at a position every lane knows in
+// advance, so that level for the first row of the NEXT set is issued before the barrier and
+// only values + x gathers remain behind it.  Values are still read from the CSR array (they
+// may change between sweeps: Galerkin rebuilds keep the schedule).  Same update, same order.
+template <int K>
+__global__ void __launch_bounds__(kSingleBlock) gs_ell_single_wg_kernel(
+    const double *vals, double *x, const double *b, const int *ell_row, const int *ell_start,
+    const int *ell_len, const int *ell_cols, int64_t total, const int *set_ptr, int64_t nsets, int sweeps)
+{
+    const int tid = threadIdx.x;
+    int p_row = 0, p_st = 0, p_len = 0, p_c[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) p_c[j] = 0;
+    auto level1 = [&](int64_t k) {
+        p_row = ell_row[k];
+        p_st = ell_start[k];
+        p_len = ell_len[k];
+#pragma unroll
+        for (int j = 0; j < K; ++j) p_c[j] = ell_cols[(int64_t)j * total + k];
+    };
+    auto relax = [&]() {
+        double v[K], xv[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            v[j] = vals[j < p_len ? p_st + j : 0];
+            xv[j] = x[p_c[j]];                      // padding columns point at the row itself
+        }
+        const double bi = b[p_row];
+        double rsum = 0.0, diag = 0.0;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (j < p_len) {
+                if (p_c[j] == p_row) diag = v[j];
+                else rsum += v[j] * xv[j];
+            }
+        }
+        if (diag != 0.0) x[p_row] = (bi - rsum) / diag;
+    };
+    {
+        const int lo = set_ptr[0], hi = set_ptr[1];
+        if (lo + tid < hi) level1(lo + tid);
+    }
+    for (int sw = 0; sw < sweeps; ++sw) {
+        for (int64_t s = 0; s < nsets; ++s) {
+            const int lo = set_ptr[s], hi = set_ptr[s + 1];
+            int k = lo + tid;
+            if (k < hi) relax();                    // first row of the lane: prefetched before the barrier
+            for (k += kSingleBlock; k < hi; k += kSingleBlock) {
+                level1(k);
+                relax();
+            }
+            // first row of the next set (wrapping to the next sweep), independent of x
+            const int64_t ns = (s + 1 < nsets) ? s + 1 : 0;
+            if (s + 1 < nsets || sw + 1 < sweeps) {
+                const int nlo = set_ptr[ns], nhi = set_ptr[ns + 1];
+                if (nlo + tid < nhi) level1(nlo + tid);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+}
+
 // Chain-like schedules (sets of one or two rows: 1-D problems, where the level schedule
 // degenerates to the sequential sweep).  One wave; the row data of 64 consecutive rows is fetched by the
 // 64 lanes at once (it does not depend on x), then the 64 rows are relaxed one after the
@@ -223,6 +290,31 @@ int lmg_csr_gs_schedule(const int32_t *rp, const int32_t *ci, const double *va, 
             hipLaunchKernelGGL(gs_rows_kernel, dim3(grid), dim3(block), 0, st, rp, ci, va, x, b,
                                d_set_rows + h_set_ptr[s], cnt);
         }
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_csr_gs_schedule_ell(const double *va, double *x, const double *b, const int32_t *d_ell_row,
+                            const int32_t *d_ell_start, const int32_t *d_ell_len, const int32_t *d_ell_cols,
+                            int32_t ell_k, int64_t total_rows, const int32_t *d_set_ptr, int64_t nsets, int sweeps,
+                            void *stream)
+{
+    if (nsets < 0 || sweeps < 0 || total_rows < 0 || !va || !x || !b) return LMG_ERR_ARG;
+    if (nsets == 0 || sweeps == 0 || total_rows == 0) return LMG_OK;
+    if (!d_ell_row || !d_ell_start || !d_ell_len || !d_ell_cols || !d_set_ptr) return LMG_ERR_ARG;
+    hipStream_t st = lmg_stream(stream);
+#define LMG_GS_ELL(KK)                                                                                      \
+    hipLaunchKernelGGL(gs_ell_single_wg_kernel<KK>, dim3(1), dim3(kSingleBlock), 0, st, va, x, b, d_ell_row, \
+                       d_ell_start, d_ell_len, d_ell_cols, total_rows, d_set_ptr, nsets, sweeps)
+    switch (ell_k) {
+    case 3: LMG_GS_ELL(3); break;
+    case 5: LMG_GS_ELL(5); break;
+    case 7: LMG_GS_ELL(7); break;
+    case 9: LMG_GS_ELL(9); break;
+    case 16: LMG_GS_ELL(16); break;
+    default: return LMG_ERR_ARG;
+    }
+#undef LMG_GS_ELL
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }

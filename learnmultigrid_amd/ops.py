@@ -420,7 +420,7 @@ def csr_spmv(A, x, y, alpha=1.0, beta=0.0):
 class GSSchedule:
     """Ordered independent sets of rows (level schedule or colour classes)."""
 
-    __slots__ = ("kind", "d_rows", "d_ptr", "h_ptr", "nsets", "max_set")
+    __slots__ = ("kind", "d_rows", "d_ptr", "h_ptr", "nsets", "max_set", "ell")
 
     def __init__(self, kind, order, ptr, device):
         self.kind = kind
@@ -429,6 +429,7 @@ class GSSchedule:
         self.d_ptr = torch.from_numpy(self.h_ptr).to(device)
         self.nsets = int(self.h_ptr.size - 1)
         self.max_set = int(np.diff(self.h_ptr).max()) if self.nsets else 0
+        self.ell = None              # pattern copy in schedule order, built on first use (see _gs_ell)
 
 
 def gs_schedule_from_labels(kind, labels, nsets, device):
@@ -460,8 +461,45 @@ def csr_gs_rows(A, x, b, rows):
                                      rows.numel(), _s()), "lmg_csr_gs_rows")
 
 
+GS_ELL_MAX_SET = 2048            # widest set the one-workgroup ELL executor takes (2 rows per lane);
+                                 # measured: at 1025^2 (sets of up to 2050 rows) per-set launches are as fast
+
+
+def _gs_ell(A, sched):
+    """Pattern of A in schedule order for lmg_csr_gs_schedule_ell, or None when the schedule
+    does not qualify (chain-like: the one-wave kernel is better; wide sets: per-set launches;
+    rows longer than 16 entries).  Built from the DEVICE arrays of the matrix it is used with."""
+    total = int(sched.h_ptr[-1]) if sched.nsets else 0
+    if total <= 4 * sched.nsets or sched.max_set > GS_ELL_MAX_SET or not A.vals.is_cuda or A.nnz == 0:
+        return None
+    key = (A.rowptr.data_ptr(), A.colidx.data_ptr(), A.nnz)
+    if sched.ell is not None and sched.ell[0] == key:
+        return sched.ell
+    rows = sched.d_rows.long()
+    start = A.rowptr[rows]
+    ln = A.rowptr[rows + 1] - start
+    kmax = int(ln.max())
+    K = next((k for k in (3, 5, 7, 9, 16) if k >= kmax), None)
+    if K is None:
+        sched.ell = (key, None)
+        return sched.ell
+    cols = torch.empty((K, total), dtype=I32, device=A.vals.device)
+    for j in range(K):
+        idx = (start + j).long().clamp(max=A.nnz - 1)
+        cols[j] = torch.where(ln > j, A.colidx[idx], sched.d_rows)
+    sched.ell = (key, K, sched.d_rows, start.contiguous(), ln.contiguous(), cols.contiguous(), total)
+    return sched.ell
+
+
 def csr_gs_schedule(A, x, b, sched, sweeps=1):
     _vec_ok(x, b)
+    ell = _gs_ell(A, sched)
+    if ell is not None and ell[1] is not None:
+        _key, K, rows, start, ln, cols, total = ell
+        check(_lib.lib().lmg_csr_gs_schedule_ell(_p(A.vals), _p(x), _p(b), _p(rows), _p(start), _p(ln), _p(cols),
+                                                 K, total, _p(sched.d_ptr), sched.nsets, int(sweeps), _s()),
+              "lmg_csr_gs_schedule_ell")
+        return
     check(_lib.lib().lmg_csr_gs_schedule(_p(A.rowptr), _p(A.colidx), _p(A.vals), _p(x), _p(b),
                                          _p(sched.d_rows), _p(sched.d_ptr), sched.h_ptr.ctypes.data,
                                          sched.nsets, sched.max_set, int(sweeps), _s()),

@@ -150,8 +150,51 @@ def test_gauss_seidel_lexicographic_bit_exact(name):
     assert np.all(lab[coo.row] != lab[coo.col])
 
 
+def test_gauss_seidel_ell_executor_and_its_fallbacks():
+    """Medium schedules run on the pattern copy in schedule order (lmg_csr_gs_schedule_ell):
+    same bits as the oracle, also after the VALUES changed (the copy only holds the pattern), and
+    a schedule used with another matrix rebuilds its copy."""
+    rng = np.random.default_rng(12)
+    for name, want_k in (("poisson2d_513", 5), ("galerkin_9pt", 9)):
+        A = case(name) if name == "poisson2d_513" else packed_case(name)
+        n = A.shape[0]
+        dA = ops.DeviceCSR.from_scipy(A, DEV)
+        sched = ops.build_gs_schedule(A, "lexicographic", DEV)
+        for trial in range(2):
+            x, b = rng.standard_normal(n), rng.standard_normal(n)
+            dx = dev(x.copy())
+            ops.csr_gs_schedule(dA, dx, dev(b), sched, sweeps=3)
+            assert sched.ell is not None and sched.ell[1] == want_k, (name, sched.ell[:2])
+            want = x.copy()
+            K.gs_forward(A, want, b, 3)
+            assert np.array_equal(dx.cpu().numpy(), want), (name, trial)
+            A = A.copy()
+            A.data = A.data * (1.0 + 0.1 * rng.random(A.nnz))          # new coefficients, same pattern
+            dA.vals.copy_(dev(A.data))
+        # the same schedule object with a second matrix of the same pattern: copy is rebuilt for it
+        dB = ops.DeviceCSR.from_scipy(A, DEV)
+        key_before = sched.ell[0]
+        dx = dev(x.copy())
+        ops.csr_gs_schedule(dB, dx, dev(b), sched, sweeps=1)
+        assert sched.ell[0] != key_before
+        want = x.copy()
+        K.gs_forward(A, want, b, 1)
+        assert np.array_equal(dx.cpu().numpy(), want)
+    # rows longer than 16 entries: no pattern copy, the CSR executors take over
+    A = case("ragged_1000")
+    sched = ops.build_gs_schedule(A, "lexicographic", DEV)
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    x, b = rng.standard_normal(A.shape[0]), rng.standard_normal(A.shape[0])
+    dx = dev(x.copy())
+    ops.csr_gs_schedule(dA, dx, dev(b), sched, sweeps=1)
+    assert sched.ell is None or sched.ell[1] is None
+    want = x.copy()
+    K.gs_forward(A, want, b, 1)
+    assert np.array_equal(dx.cpu().numpy(), want)
+
+
 def test_gauss_seidel_wide_sets_use_per_set_launches():
-    # 513^2 has 1025 anti-diagonal sets of up to 513 rows -> single-workgroup path;
+    # 513^2 has 1025 anti-diagonal sets of up to 513 rows -> one-workgroup path;
     # a 2100^2 grid has sets of up to 2100 rows (> 2048) -> per-set launch path.
     A, _ = P.poisson_2d_structured(2100 - 1)
     A = K.as_csr(A)
@@ -164,7 +207,7 @@ def test_gauss_seidel_wide_sets_use_per_set_launches():
     ops.csr_gs_schedule(dA, dx, dev(b), sched, sweeps=1)
     want = x.copy()
     K.gs_forward(A, want, b, 1)
-    assert sched.max_set > 2048
+    assert sched.max_set > ops.GS_ELL_MAX_SET and sched.ell is None
     assert np.array_equal(dx.cpu().numpy(), want)
 
 

@@ -26,7 +26,7 @@ for name, A in cases:
     db = torch.from_numpy(b).cuda()
     w = x0.copy()
     t = time.perf_counter(); K.gs_forward(A, w, b, 1); dc = time.perf_counter() - t
-    for single_max in ((2048, 1 << 30) if big else (2048,)):
+    for single_max in (2048,):
         ops.tune_set("gs_single_max", single_max)
         x = torch.from_numpy(x0.copy()).cuda()
         ops.csr_gs_schedule(dA, x, db, sch, 1); torch.cuda.synchronize()

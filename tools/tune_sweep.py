@@ -32,6 +32,15 @@ def main():
     A, rhs = P.poisson_2d_structured(m)
     if args.matrix == "A0":
         M = A
+    elif args.matrix in ("L1", "L2"):
+        # learned-like (pseudo-L2 support, perturbed weights) Galerkin operators: 25 / ~48 entries per row
+        Av, _ = P.variable_coeff_poisson_2d_structured(m, seed=44)
+        M = Av
+        for li, sz in enumerate(P.level_sizes(m + 1, 3)[:2 if args.matrix == "L2" else 1]):
+            l2 = P.pseudo_l2_interpolator_1d(sz)
+            Q = P.learned_like(sp.kron(l2, l2).tocsr(), 43 + li)
+            M = sp.csr_matrix(Q.T @ M @ Q)
+        M.sort_indices()
     else:
         Pm = P.tensor_interpolator_2d(m + 1)
         M = {"A1": lambda: sp.csr_matrix(Pm.T @ A @ Pm), "P0": lambda: Pm,

@@ -127,6 +127,26 @@ int lmg_rpat_verify(int64_t n, int64_t ncols, const int32_t *d_rowptr, const int
                     const double *d_vals, const uint8_t *d_pid, int32_t npat, const int32_t *d_pat_ptr,
                     const int32_t *d_pat_off, const double *d_pat_val, int32_t *d_mismatch, void *stream);
 
+/* ---- sliced-ELL ("SELL-64") sweeps: matrices with long rows ---------------------------
+ * Third lossless twin.  Slice s = rows 64 s .. 64 s + 63, padded to its longest row
+ * d_slice_len[s]; entry j of row r lives at d_slice_base[s] + 64 j + (r mod 64) of d_col
+ * (colmode 0: uint16 column - d_slice_cmin[s]; 1: int32 column) and d_val (fp64), so a wave
+ * reads entry j of its 64 rows with one coalesced load per stream and needs no LDS.  Rows are
+ * still accumulated in storage order: same bits as the CSR entry points.  d_rowlen[n] = true
+ * row lengths; max_len = longest row (picks the unrolling); modes and arguments as
+ * lmg_pcsr_sweep.  Building: lmg_sell_slice_info (padded length and column range per slice),
+ * d_slice_base = exclusive int64 scan of 64 * d_slice_len, lmg_sell_fill (d_col_out may be NULL
+ * to refresh the values only); the padded arrays must be zero-initialised. */
+int lmg_sell_sweep(int mode, int64_t n, const int64_t *d_slice_base, const int32_t *d_slice_len,
+                   const int32_t *d_slice_cmin, const int32_t *d_rowlen, const void *d_col, int colmode,
+                   const double *d_val, int32_t max_len, const double *d_x, const double *d_b, double *d_out,
+                   double alpha, double beta, double *d_partials, double *d_norm2, void *stream);
+int lmg_sell_slice_info(int64_t n, const int32_t *d_rowptr, const int32_t *d_colidx, int32_t *d_slice_len,
+                        int32_t *d_cmin, int32_t *d_cmax, void *stream);
+int lmg_sell_fill(int64_t n, const int32_t *d_rowptr, const int32_t *d_colidx, const double *d_vals,
+                  const int64_t *d_slice_base, const int32_t *d_slice_cmin, int colmode, void *d_col_out,
+                  double *d_val_out, void *stream);
+
 /* ---- building the packed twin (setup) ----------------------------------------------
  * One streaming pass each; learnmultigrid_amd/ops.py PackedCSR.from_csr is the calling sequence.
  *   lmg_pcsr_tile_colrange   smallest / largest column of every tile of `tile_rows` rows

@@ -41,6 +41,9 @@ SIGNATURES = {
     "lmg_rpat_row_hash": (_c.c_int, [_i64, _p, _p, _p, _p, _p]),
     "lmg_rpat_claim": (_c.c_int, [_i64, _p, _p, _p]),
     "lmg_rpat_verify": (_c.c_int, [_i64, _i64, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
+    "lmg_sell_sweep": (_c.c_int, [_c.c_int, _i64, _p, _p, _p, _p, _p, _c.c_int, _p, _i32, _p, _p, _p, _f64, _f64, _p, _p, _p]),
+    "lmg_sell_slice_info": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p]),
+    "lmg_sell_fill": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _c.c_int, _p, _p, _p]),
     "lmg_pcsr_tile_colrange": (_c.c_int, [_i64, _i32, _p, _p, _p, _p, _p]),
     "lmg_pcsr_encode_cols16": (_c.c_int, [_i64, _i32, _p, _p, _p, _p, _p]),
     "lmg_value_set_insert": (_c.c_int, [_i64, _p, _p, _i64, _i32, _p, _p]),

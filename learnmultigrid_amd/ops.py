@@ -37,7 +37,7 @@ def _vec_ok(*ts):
 class DeviceCSR:
     """CSR matrix resident in HBM: int32 rowptr[n+1], int32 colidx[nnz], fp64 vals[nnz]."""
 
-    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz", "packed", "patterns")
+    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz", "packed", "patterns", "sell")
 
     def __init__(self, rowptr, colidx, vals, shape):
         if rowptr.dtype != I32 or colidx.dtype != I32 or vals.dtype != F64:
@@ -49,6 +49,7 @@ class DeviceCSR:
         self.nnz = int(vals.numel())
         self.packed = None           # PackedCSR twin used by the sweeps once pack() was called
         self.patterns = None         # RowPatterns twin (matrices with repeating rows), preferred
+        self.sell = None             # SellCSR twin (long rows with all-distinct values)
 
     def pack(self, patterns=None):
         """Build (once) the lossless twin the sweep kernels prefer; keeps the CSR arrays.
@@ -62,13 +63,25 @@ class DeviceCSR:
             self.patterns = RowPatterns.from_csr(self)
         if patterns and self.patterns is not None:
             return self.patterns
+        if self.sell is not None:
+            return self.sell
         if self.packed is None:
             self.packed = PackedCSR.from_csr(self)
+            # long rows whose values do not fit a dictionary: the sliced-ELL twin reads them without
+            # LDS staging (the packed kernel's row-strided LDS walk is bank-conflict-bound there)
+            pk = self.packed
+            if (_SELL_ENABLED and pk is not None and pk.valmode == 2 and pk.tile_rows < 512
+                    and self.nnz >= SELL_MIN_AVG * self.shape[0]):
+                self.sell = SellCSR.from_csr(self)
+                if self.sell is not None:
+                    self.packed = None
+                    return self.sell
         return self.packed
 
     def invalidate_packed(self):
         self.packed = None
         self.patterns = None
+        self.sell = None
 
     def repack_values(self):
         """After the values changed in place: refresh the twins (cheaply if possible)."""
@@ -76,6 +89,8 @@ class DeviceCSR:
             self.patterns = RowPatterns.from_csr(self)
             if self.patterns is None:
                 self.pack()
+        if self.sell is not None:
+            self.sell.update_values(self)
         if self.packed is not None and not self.packed.update_values(self):
             self.packed = None
             self.pack(patterns=False)
@@ -263,6 +278,59 @@ class PackedCSR:
         return True
 
 
+class SellCSR:
+    """Sliced-ELL (SELL-64) twin of a DeviceCSR for lmg_sell_sweep (see include/lmg.h): slices of 64
+    rows padded to their longest row, entries stored column-major inside a slice.  For long rows
+    with all-distinct values (Galerkin operators of learned / L2-type transfers); refused when the
+    padding would cost more than 20 % extra entries."""
+
+    __slots__ = ("n", "nnz", "shape", "slice_base", "slice_len", "slice_cmin", "rowlen", "col", "colmode", "val",
+                 "max_len", "padded", "bytes_")
+
+    MAX_PADDING = 1.2
+
+    @classmethod
+    def from_csr(cls, A):
+        n, nnz = A.shape[0], A.nnz
+        if n == 0 or nnz == 0 or not A.vals.is_cuda:
+            return None
+        L = _lib.lib()
+        dev = A.vals.device
+        nsl = (n + 63) // 64
+        slice_len = torch.empty(nsl, dtype=I32, device=dev)
+        cmin = torch.empty(nsl, dtype=I32, device=dev)
+        cmax = torch.empty(nsl, dtype=I32, device=dev)
+        check(L.lmg_sell_slice_info(n, _p(A.rowptr), _p(A.colidx), _p(slice_len), _p(cmin), _p(cmax), _s()),
+              "lmg_sell_slice_info")
+        padded = 64 * int(slice_len.long().sum())
+        if padded > cls.MAX_PADDING * nnz or padded >= 2 ** 31 - 64:
+            return None
+        self = cls()
+        self.n, self.nnz, self.shape, self.padded = n, nnz, A.shape, padded
+        sl = slice_len.long() * 64
+        self.slice_base = (torch.cumsum(sl, 0) - sl).contiguous()
+        self.slice_len = slice_len
+        self.slice_cmin = cmin
+        self.rowlen = (A.rowptr[1:] - A.rowptr[:-1]).contiguous()
+        self.max_len = int(slice_len.max())
+        self.colmode = 0 if int((cmax - cmin).max()) < 65536 else 1
+        self.col = torch.zeros(padded + 64, dtype=torch.int16 if self.colmode == 0 else I32, device=dev)
+        self.val = torch.zeros(padded + 64, dtype=F64, device=dev)
+        check(L.lmg_sell_fill(n, _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(self.slice_base), _p(cmin), self.colmode,
+                              _p(self.col), _p(self.val), _s()), "lmg_sell_fill")
+        self.bytes_ = padded * ((2, 4)[self.colmode] + 8) + 16 * nsl + 4 * n
+        return self
+
+    def bytes(self):
+        return int(self.bytes_)
+
+    def update_values(self, A):
+        """New values, same pattern (Galerkin rebuild): only the value stream is rewritten."""
+        check(_lib.lib().lmg_sell_fill(self.n, _p(A.rowptr), None, _p(A.vals), _p(self.slice_base), _p(self.slice_cmin),
+                                       self.colmode, None, _p(self.val), _s()), "lmg_sell_fill(values)")
+        return True
+
+
 class RowPatterns:
     """Lossless row-pattern twin of a DeviceCSR for lmg_rpat_sweep (see include/lmg.h): every
     distinct row -- (length; column - row and value bits of each entry, in storage order) -- is
@@ -328,6 +396,20 @@ class RowPatterns:
 
 _PACKED_ENABLED = True
 _PATTERNS_ENABLED = True
+_SELL_ENABLED = True
+SELL_MIN_AVG = 12.0          # average row length from which the sliced-ELL twin replaces the packed CSR
+
+
+def set_sell_enabled(flag):
+    """Whether pack() may pick the sliced-ELL twin for long rows (default) or keeps the packed CSR."""
+    global _SELL_ENABLED
+    _SELL_ENABLED = bool(flag)
+
+
+def _sell(mode, S, x, b, out, alpha, beta, partials, norm2):
+    return _lib.lib().lmg_sell_sweep(mode, S.n, _p(S.slice_base), _p(S.slice_len), _p(S.slice_cmin), _p(S.rowlen),
+                                     _p(S.col), S.colmode, _p(S.val), S.max_len, _p(x), _p(b), _p(out), float(alpha),
+                                     float(beta), _p(partials), _p(norm2), _s())
 
 
 def set_packed_enabled(flag):
@@ -376,6 +458,9 @@ def csr_residual_norm2(A, x, b, r, partials, norm2):
     if _PACKED_ENABLED and A.patterns is not None:
         check(_rpat(0, A.patterns, x, b, r, 0.0, 0.0, partials, norm2), "lmg_rpat_sweep(residual)")
         return
+    if _PACKED_ENABLED and A.sell is not None:
+        check(_sell(0, A.sell, x, b, r, 0.0, 0.0, partials, norm2), "lmg_sell_sweep(residual)")
+        return
     if _PACKED_ENABLED and A.packed is not None:
         rc = _pcsr(0, A.packed, x, b, r, 0.0, 0.0, partials, norm2)
         if rc != -4:                                   # LMG_ERR_CAPACITY: tile too large for LDS
@@ -390,6 +475,9 @@ def csr_jacobi(A, x_in, b, omega, x_out):
     _vec_ok(x_in, b, x_out)
     if _PACKED_ENABLED and A.patterns is not None:
         check(_rpat(1, A.patterns, x_in, b, x_out, omega, 0.0, None, None), "lmg_rpat_sweep(jacobi)")
+        return
+    if _PACKED_ENABLED and A.sell is not None:
+        check(_sell(1, A.sell, x_in, b, x_out, omega, 0.0, None, None), "lmg_sell_sweep(jacobi)")
         return
     if _PACKED_ENABLED and A.packed is not None:
         rc = _pcsr(1, A.packed, x_in, b, x_out, omega, 0.0, None, None)
@@ -406,6 +494,9 @@ def csr_spmv(A, x, y, alpha=1.0, beta=0.0):
         raise ValueError("spmv shape mismatch: A %s, x %d, y %d" % (A.shape, x.numel(), y.numel()))
     if _PACKED_ENABLED and A.patterns is not None:
         check(_rpat(2, A.patterns, x, None, y, alpha, beta, None, None), "lmg_rpat_sweep(spmv)")
+        return
+    if _PACKED_ENABLED and A.sell is not None:
+        check(_sell(2, A.sell, x, None, y, alpha, beta, None, None), "lmg_sell_sweep(spmv)")
         return
     if _PACKED_ENABLED and A.packed is not None:
         rc = _pcsr(2, A.packed, x, None, y, alpha, beta, None, None)

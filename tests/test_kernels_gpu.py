@@ -492,8 +492,12 @@ def test_packed_sweeps_bit_exact(name):
     rng = np.random.default_rng(21)
     x, b, y0 = rng.standard_normal(m), rng.standard_normal(n), rng.standard_normal(n)
     dA = ops.DeviceCSR.from_scipy(A, DEV)
-    Pk = dA.pack(patterns=False)
-    assert Pk is not None and dA.patterns is None
+    ops.set_sell_enabled(False)                  # this test is about the packed CSR kernels
+    try:
+        Pk = dA.pack(patterns=False)
+    finally:
+        ops.set_sell_enabled(True)
+    assert Pk is not None and dA.patterns is None and dA.sell is None
     want_modes = {"val8": 0, "val16": 1, "val64": 2}
     for key, vm in want_modes.items():
         if name.startswith(key):
@@ -579,7 +583,11 @@ def _numpy_pack(A, T):
 def test_packed_format_matches_its_numpy_restatement(name):
     A = packed_case(name)
     dA = ops.DeviceCSR.from_scipy(A, DEV)
-    Pk = dA.pack(patterns=False)
+    ops.set_sell_enabled(False)
+    try:
+        Pk = dA.pack(patterns=False)
+    finally:
+        ops.set_sell_enabled(True)
     base, cmin, cmax, rel, uniq, idx = _numpy_pack(A, Pk.tile_rows)
     nnz = A.nnz
     assert np.array_equal(Pk.tile_base.cpu().numpy(), base)
@@ -846,3 +854,96 @@ def test_row_patterns_are_refused_when_rows_do_not_repeat():
     assert dA.patterns is None and dA.packed is not None
     ops.csr_spmv(dA, dev(x), y)
     assert np.array_equal(y.cpu().numpy(), K.spmv(B, x, np.zeros_like(x), 1.0, 0.0))
+
+
+# ---- sliced-ELL twin (sell.hip) ----------------------------------------------------------------
+@functools.lru_cache(maxsize=None)
+def sell_case(name):
+    if name == "l2_galerkin_25":
+        return packed_case("val64_longrows_l2_galerkin")
+    if name == "l2_galerkin_48":                      # second Galerkin level of learned-like transfers
+        A2, _ = P.variable_coeff_poisson_2d_structured(128, seed=44)
+        M = A2
+        for li, sz in enumerate((129, 65)):
+            l2 = P.pseudo_l2_interpolator_1d(sz)
+            Q = P.learned_like(sp.kron(l2, l2).tocsr(), 43 + li)
+            M = sp.csr_matrix(Q.T @ M @ Q)
+        return K.as_csr(M)
+    if name == "random_wide_20":                      # columns all over the place: int32 columns
+        rng = np.random.default_rng(17)
+        n = 70001                                     # not a multiple of 64: ragged last slice
+        r = np.repeat(np.arange(n), 19)               # 19 random columns in EVERY row: near-uniform lengths
+        c = rng.integers(0, n, r.size)
+        return K.as_csr(sp.coo_matrix((rng.standard_normal(r.size), (r, c)), shape=(n, n)).tocsr() + sp.identity(n) * 5.0)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["l2_galerkin_25", "l2_galerkin_48", "random_wide_20"])
+def test_sliced_ell_sweeps_bit_exact(name):
+    A = sell_case(name)
+    n = A.shape[0]
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    S = dA.pack()
+    assert isinstance(S, ops.SellCSR) and dA.packed is None and dA.patterns is None, name
+    assert S.colmode == (1 if name == "random_wide_20" else 0)
+    # the format, restated: slices of 64 rows padded to their longest row, column-major inside a slice
+    lens = np.diff(A.indptr)
+    nsl = (n + 63) // 64
+    padded_lens = np.array([lens[s * 64:(s + 1) * 64].max() for s in range(nsl)])
+    assert np.array_equal(S.slice_len.cpu().numpy(), padded_lens)
+    base = np.concatenate([[0], np.cumsum(padded_lens * 64)[:-1]])
+    assert np.array_equal(S.slice_base.cpu().numpy(), base) and S.padded == int(padded_lens.sum()) * 64
+    val, col = S.val.cpu().numpy(), S.col.cpu().numpy()
+    cmin = S.slice_cmin.cpu().numpy()
+    for r in (0, 1, 63, 64, n // 2, n - 1):
+        s, e = A.indptr[r], A.indptr[r + 1]
+        pos = base[r // 64] + 64 * np.arange(e - s) + (r % 64)
+        assert np.array_equal(val[pos], A.data[s:e])
+        got_cols = col[pos].astype(np.int64)
+        if S.colmode == 0:
+            got_cols = (got_cols & 0xFFFF) + cmin[r // 64]
+        assert np.array_equal(got_cols, A.indices[s:e])
+    rng = np.random.default_rng(29)
+    x, b, y0 = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
+    try:
+        for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (-0.5, 2.0)):
+            y = dev(y0.copy())
+            ops.csr_spmv(dA, dev(x), y, alpha, beta)
+            assert np.array_equal(y.cpu().numpy(), K.spmv(A, x, y0, alpha, beta)), (name, alpha, beta)
+        r = torch.empty(n, dtype=torch.float64, device=DEV)
+        part = torch.empty(ops.partials_count(n), dtype=torch.float64, device=DEV)
+        n2 = torch.zeros(1, dtype=torch.float64, device=DEV)
+        ops.csr_residual_norm2(dA, dev(x), dev(b), r, part, n2)
+        wr, wn2 = K.residual(A, x, b)
+        assert np.array_equal(r.cpu().numpy(), wr)
+        assert abs(n2.item() - wn2) <= 1e-13 * wn2
+        n2b = torch.zeros(1, dtype=torch.float64, device=DEV)
+        ops.csr_residual_norm2(dA, dev(x), dev(b), None, part, n2b)
+        assert n2b.item() == n2.item()
+        for omega in (1.0, 0.8):
+            out = torch.empty(n, dtype=torch.float64, device=DEV)
+            ops.csr_jacobi(dA, dev(x), dev(b), omega, out)
+            assert np.array_equal(out.cpu().numpy(), K.jacobi(A, x, b, omega)), (name, omega)
+        ops.set_packed_enabled(False)
+        out2 = torch.empty(n, dtype=torch.float64, device=DEV)
+        ops.csr_jacobi(dA, dev(x), dev(b), 0.8, out2)
+        assert torch.equal(out, out2)
+        ops.set_packed_enabled(True)
+        # new values on the same pattern (Galerkin rebuild): only the value stream is rewritten
+        B = A.copy()
+        B.data = rng.standard_normal(B.nnz)
+        dA.vals.copy_(dev(B.data))
+        dA.repack_values()
+        assert dA.sell is S
+        ops.csr_jacobi(dA, dev(x), dev(b), 0.8, out)
+        assert np.array_equal(out.cpu().numpy(), K.jacobi(B, x, b, 0.8))
+    finally:
+        ops.set_packed_enabled(True)
+
+
+def test_sliced_ell_is_refused_for_ragged_rows():
+    # one very long row per slice would pad every slice to its length
+    A = case("ragged_1000")
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    dA.pack()
+    assert dA.sell is None

@@ -30,8 +30,14 @@ def main():
     dev = "cuda:0"
     m = args.size
     A, rhs = P.poisson_2d_structured(m)
+    if os.environ.get("LMG_SELL_MIN_AVG"):
+        ops.SELL_MIN_AVG = float(os.environ["LMG_SELL_MIN_AVG"])
     if args.matrix == "A0":
         M = A
+    elif args.matrix == "V0":                         # variable coefficients: 5 entries per row, all values distinct
+        M = P.variable_coeff_poisson_2d_structured(m, seed=44)[0]
+    elif args.matrix == "J0":                         # jittered mesh: 7 entries per row, all values distinct
+        M = P.jittered_poisson_2d(m, seed=42)[0] if hasattr(P, "jittered_poisson_2d") else A
     elif args.matrix in ("L1", "L2"):
         # learned-like (pseudo-L2 support, perturbed weights) Galerkin operators: 25 / ~48 entries per row
         Av, _ = P.variable_coeff_poisson_2d_structured(m, seed=44)
@@ -66,7 +72,7 @@ def main():
     jus = [int(v) for v in args.ju.split(",")] if args.ju else []
     if args.packed:
         pk = dM.pack()
-        print("packed: colmode %d valmode %d ndict %d bytes %d (csr %d)" % (pk.colmode, pk.valmode, pk.ndict, pk.bytes(), dM.bytes()))
+        print("twin: %s, %d bytes (csr %d)" % (type(pk).__name__, pk.bytes(), dM.bytes()))
         variants = ([-j for j in jus] if jus else [-1]) + variants
     ops.set_packed_enabled(False)
     times = {v: [] for v in variants}

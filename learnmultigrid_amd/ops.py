@@ -70,8 +70,9 @@ class DeviceCSR:
             # long rows whose values do not fit a dictionary: the sliced-ELL twin reads them without
             # LDS staging (the packed kernel's row-strided LDS walk is bank-conflict-bound there)
             pk = self.packed
-            if (_SELL_ENABLED and pk is not None and pk.valmode == 2 and pk.tile_rows < 512
-                    and self.nnz >= SELL_MIN_AVG * self.shape[0]):
+            long_raw = pk is not None and pk.valmode == 2 and pk.tile_rows < 512
+            unpackable = pk is None and self.nnz > 0           # rows longer than 255 entries (dense-ish operators)
+            if _SELL_ENABLED and (long_raw or unpackable) and self.nnz >= SELL_MIN_AVG * self.shape[0]:
                 self.sell = SellCSR.from_csr(self)
                 if self.sell is not None:
                     self.packed = None

@@ -869,6 +869,9 @@ def sell_case(name):
             Q = P.learned_like(sp.kron(l2, l2).tocsr(), 43 + li)
             M = sp.csr_matrix(Q.T @ M @ Q)
         return K.as_csr(M)
+    if name == "dense_rows_300":                      # dense transfer operators give rows beyond the packed limit of 255
+        rng = np.random.default_rng(19)
+        return K.as_csr(sp.csr_matrix(rng.standard_normal((300, 300)) + 300.0 * np.eye(300)))
     if name == "random_wide_20":                      # columns all over the place: int32 columns
         rng = np.random.default_rng(17)
         n = 70001                                     # not a multiple of 64: ragged last slice
@@ -878,7 +881,7 @@ def sell_case(name):
     raise KeyError(name)
 
 
-@pytest.mark.parametrize("name", ["l2_galerkin_25", "l2_galerkin_48", "random_wide_20"])
+@pytest.mark.parametrize("name", ["l2_galerkin_25", "l2_galerkin_48", "random_wide_20", "dense_rows_300"])
 def test_sliced_ell_sweeps_bit_exact(name):
     A = sell_case(name)
     n = A.shape[0]

@@ -44,7 +44,10 @@ struct RArgs {
     double *partial;
 };
 
-template <int MODE, int JU, int kRpt>
+// NT: the streams without reuse (pattern ids, b, out) bypass the caches.  It pays when the vectors do
+// not fit the 256 MB Infinity Cache anyway (cfg#4 fine level: -8 %) and costs 20 % when they do
+// (2049^2), so the launcher turns it on from 8 M rows.
+template <int MODE, int JU, int kRpt, bool NT>
 __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
 {
     constexpr int kTileRows = kBlock * kRpt;
@@ -91,8 +94,8 @@ __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
 #pragma unroll
         for (int k = 0; k < kRpt; ++k) {
             const int r = tl * kTileRows + k * kBlock + t;
-            pat[k] = r < a.n ? (int)a.pid[r] : 0;
-            bv[k] = (MODE != MODE_SPMV && r < a.n) ? a.b[r] : 0.0;
+            pat[k] = r < a.n ? (int)(NT ? __builtin_nontemporal_load(a.pid + r) : a.pid[r]) : 0;
+            bv[k] = (MODE != MODE_SPMV && r < a.n) ? (NT ? __builtin_nontemporal_load(a.b + r) : a.b[r]) : 0.0;
         }
     };
     auto process = [&](int tile, const int (&pat)[kRpt], const double (&bv)[kRpt]) {
@@ -151,17 +154,26 @@ __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
             if (row[k] < a.n) {
                 if (MODE == MODE_RESIDUAL) {
                     const double r = bv[k] - acc[k];
-                    if (a.out) a.out[row[k]] = r;
+                    if (a.out) {
+                        if (NT) __builtin_nontemporal_store(r, a.out + row[k]);
+                        else a.out[row[k]] = r;
+                    }
                     local += r * r;
                 } else if (MODE == MODE_JACOBI) {
                     const double r = bv[k] - acc[k];
-                    if (s_diag[pat[k]] != 0.0) a.out[row[k]] = xi[k] + a.alpha * (s_rdiag[pat[k]] * r);
+                    if (s_diag[pat[k]] != 0.0) {
+                        const double o = xi[k] + a.alpha * (s_rdiag[pat[k]] * r);
+                        if (NT) __builtin_nontemporal_store(o, a.out + row[k]);
+                        else a.out[row[k]] = o;
+                    }
                     else a.out[row[k]] = a.x[row[k]];
                 } else {
                     double s = acc[k];
                     if (a.alpha != 1.0) s = a.alpha * s;
-                    if (a.beta == 0.0) a.out[row[k]] = s;
-                    else if (a.beta == 1.0) a.out[row[k]] = a.out[row[k]] + s;
+                    if (a.beta == 0.0) {
+                        if (NT) __builtin_nontemporal_store(s, a.out + row[k]);
+                        else a.out[row[k]] = s;
+                    } else if (a.beta == 1.0) a.out[row[k]] = a.out[row[k]] + s;
                     else a.out[row[k]] = a.beta * a.out[row[k]] + s;
                 }
             }
@@ -206,21 +218,29 @@ __global__ void __launch_bounds__(1024) rpat_reduce_partials_kernel(const double
 
 int g_rpat_variant = 0;      // 0 = pick from the longest pattern; 1..4 = forced (tuning)
 
-template <int MODE, int JU, int kRpt>
-int launch_one(RArgs a, hipStream_t st)
+template <int MODE, int JU, int kRpt, bool NT>
+int launch_nt(RArgs a, hipStream_t st)
 {
     a.tiles = (a.n + kBlock * kRpt - 1) / (kBlock * kRpt);
     a.tiles_per_xcd = (a.tiles + 7) / 8;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rpat_sweep_kernel<MODE, JU, kRpt>, kBlock, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rpat_sweep_kernel<MODE, JU, kRpt, NT>, kBlock, 0) !=
             hipSuccess || per_cu < 1)
         per_cu = 4;
     if (per_cu > 8) per_cu = 8;
     int64_t grid = 256 * (int64_t)per_cu;
     if (grid > (int64_t)a.tiles_per_xcd * 8) grid = (int64_t)a.tiles_per_xcd * 8;
-    hipLaunchKernelGGL((rpat_sweep_kernel<MODE, JU, kRpt>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((rpat_sweep_kernel<MODE, JU, kRpt, NT>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
     LMG_CHECK_LAUNCH();
     return a.tiles;
+}
+
+constexpr int kNontemporalRows = 1 << 23;
+
+template <int MODE, int JU, int kRpt>
+int launch_one(RArgs a, hipStream_t st)
+{
+    return a.n >= kNontemporalRows ? launch_nt<MODE, JU, kRpt, true>(a, st) : launch_nt<MODE, JU, kRpt, false>(a, st);
 }
 
 template <int MODE>

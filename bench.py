@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB
 # HBM bytes per launch of the fine-level Jacobi sweep from rocprofv3 PMC passes
 # (2 x FETCH_SIZE [gfx950 counts wide reads at half size] + WRITE_SIZE, KB -> B), keyed by
 # (--size, fine-level format); see profiles/ for the runs these come from.  None = not measured.
-PMC_TRAFFIC = {(4096, "csr"): 1485261824, (4096, "pcsr"): 672639665, (4096, "rpat"): 448400460}
+PMC_TRAFFIC = {(4096, "csr"): 1485261824, (4096, "pcsr"): 672639665, (4096, "rpat"): 451701453}
 
 
 def sweep_bytes(n, nnz):

@@ -291,7 +291,7 @@ def test_exclusive_scan_bit_exact(n):
 
 
 SPGEMM = ["RA_2d", "RA_P_2d", "QtA_l2like", "QtAQ_l2like", "QtA_level1_l2like", "RA_1d", "ragged_sq",
-          "ragged_medium", "empty_rows"]
+          "ragged_medium", "ragged_large", "empty_rows"]
 
 
 @functools.lru_cache(maxsize=None)
@@ -319,6 +319,9 @@ def spgemm_case(name):
     if name == "ragged_medium":                  # ~2000 products in one row: 256-thread class
         med = ragged_matrix(3000, 4, long_row=29, long_len=300)
         return med, med
+    if name == "ragged_large":                   # ~4000 products in one row: the 8192-slot class (sort and replay)
+        big = ragged_matrix(3000, 5, long_row=31, long_len=700)
+        return big, big
     if name == "empty_rows":
         return sp.csr_matrix((5, 4)), sp.csr_matrix((4, 6))
     raise KeyError(name)
@@ -334,6 +337,8 @@ def test_spgemm_matches_scipy_bit_exact(name):
         assert plan.max_products > 8192 and plan.long_rows is not None and plan.long_rows.numel() >= 1
     if name == "ragged_medium":
         assert 1024 < plan.max_products <= 8192               # exercises the 256-thread class
+    if name == "ragged_large":
+        assert 2048 < plan.max_products <= 8192, plan.max_products   # replay: the 8192-slot class
     C = plan.numeric(dA, dB).to_scipy()
     want = sp.csr_matrix(A @ B)
     want.sort_indices()

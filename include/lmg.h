@@ -196,8 +196,9 @@ int lmg_csr_gs_schedule(const int32_t *d_rowptr, const int32_t *d_colidx, const 
  * k-th scheduled row, d_ell_start[k] / d_ell_len[k] its entry range in the CSR arrays,
  * d_ell_cols[j * total_rows + k] its j-th column (j < ell_k in {3, 5, 7, 9, 16} >= the longest
  * row; padding entries hold the row itself).  Values are read from d_vals, so the copy stays
- * valid across coefficient changes.  Same results as lmg_csr_gs_schedule, bit for bit. */
-int lmg_csr_gs_schedule_ell(const double *d_vals, double *d_x, const double *d_b, const int32_t *d_ell_row,
+ * valid across coefficient changes.  n = length of d_x (up to 18 000 unknowns the iterate is kept
+ * in LDS for the whole call).  Same results as lmg_csr_gs_schedule, bit for bit. */
+int lmg_csr_gs_schedule_ell(int64_t n, const double *d_vals, double *d_x, const double *d_b, const int32_t *d_ell_row,
                             const int32_t *d_ell_start, const int32_t *d_ell_len, const int32_t *d_ell_cols,
                             int32_t ell_k, int64_t total_rows, const int32_t *d_set_ptr, int64_t nsets,
                             int sweeps, void *stream);

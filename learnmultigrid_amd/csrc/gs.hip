@@ -69,12 +69,21 @@ __global__ void __launch_bounds__(kSingleBlock) gs_single_wg_kernel(
 // advance, so that level for the first row of the NEXT set is issued before the barrier and
 // only values + x gathers remain behind it.  Values are still read from the CSR array (they
 // may change between sweeps: Galerkin rebuilds keep the schedule).  Same update, same order.
-template <int K>
+// X_IN_LDS: the whole iterate lives in LDS for the duration of the kernel (small grids, up to
+// 18 000 unknowns): between two sets there is then only a workgroup barrier, no round trip
+// through L2.
+template <int K, bool X_IN_LDS>
 __global__ void __launch_bounds__(kSingleBlock) gs_ell_single_wg_kernel(
-    const double *vals, double *x, const double *b, const int *ell_row, const int *ell_start,
-    const int *ell_len, const int *ell_cols, int64_t total, const int *set_ptr, int64_t nsets, int sweeps)
+    const double *vals, double *xg, const double *b, const int *ell_row, const int *ell_start,
+    const int *ell_len, const int *ell_cols, int64_t total, const int *set_ptr, int64_t nsets, int sweeps, int n)
 {
+    extern __shared__ double s_xl[];
     const int tid = threadIdx.x;
+    double *x = X_IN_LDS ? s_xl : xg;
+    if (X_IN_LDS) {
+        for (int i = tid; i < n; i += kSingleBlock) s_xl[i] = xg[i];
+        __syncthreads();
+    }
     int p_row = 0, p_st = 0, p_len = 0, p_c[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) p_c[j] = 0;
@@ -126,6 +135,9 @@ __global__ void __launch_bounds__(kSingleBlock) gs_ell_single_wg_kernel(
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
+    }
+    if (X_IN_LDS) {
+        for (int i = tid; i < n; i += kSingleBlock) xg[i] = s_xl[i];
     }
 }
 
@@ -294,18 +306,33 @@ int lmg_csr_gs_schedule(const int32_t *rp, const int32_t *ci, const double *va, 
     return LMG_OK;
 }
 
-int lmg_csr_gs_schedule_ell(const double *va, double *x, const double *b, const int32_t *d_ell_row,
+int lmg_csr_gs_schedule_ell(int64_t n, const double *va, double *x, const double *b, const int32_t *d_ell_row,
                             const int32_t *d_ell_start, const int32_t *d_ell_len, const int32_t *d_ell_cols,
                             int32_t ell_k, int64_t total_rows, const int32_t *d_set_ptr, int64_t nsets, int sweeps,
                             void *stream)
 {
+    if (n < 0 || n >= INT32_MAX) return LMG_ERR_ARG;
     if (nsets < 0 || sweeps < 0 || total_rows < 0 || !va || !x || !b) return LMG_ERR_ARG;
     if (nsets == 0 || sweeps == 0 || total_rows == 0) return LMG_OK;
     if (!d_ell_row || !d_ell_start || !d_ell_len || !d_ell_cols || !d_set_ptr) return LMG_ERR_ARG;
     hipStream_t st = lmg_stream(stream);
-#define LMG_GS_ELL(KK)                                                                                      \
-    hipLaunchKernelGGL(gs_ell_single_wg_kernel<KK>, dim3(1), dim3(kSingleBlock), 0, st, va, x, b, d_ell_row, \
-                       d_ell_start, d_ell_len, d_ell_cols, total_rows, d_set_ptr, nsets, sweeps)
+    const size_t lds = (size_t)n * sizeof(double);
+    const bool in_lds = lds <= 144 * 1024;
+#define LMG_GS_ELL(KK)                                                                                               \
+    do {                                                                                                             \
+        if (in_lds) {                                                                                                \
+            if (lds > 48 * 1024)                                                                                     \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gs_ell_single_wg_kernel<KK, true>),         \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+            hipLaunchKernelGGL((gs_ell_single_wg_kernel<KK, true>), dim3(1), dim3(kSingleBlock), lds, st, va, x, b,  \
+                               d_ell_row, d_ell_start, d_ell_len, d_ell_cols, total_rows, d_set_ptr, nsets, sweeps,  \
+                               (int)n);                                                                              \
+        } else {                                                                                                     \
+            hipLaunchKernelGGL((gs_ell_single_wg_kernel<KK, false>), dim3(1), dim3(kSingleBlock), 0, st, va, x, b,   \
+                               d_ell_row, d_ell_start, d_ell_len, d_ell_cols, total_rows, d_set_ptr, nsets, sweeps,  \
+                               (int)n);                                                                              \
+        }                                                                                                            \
+    } while (0)
     switch (ell_k) {
     case 3: LMG_GS_ELL(3); break;
     case 5: LMG_GS_ELL(5); break;

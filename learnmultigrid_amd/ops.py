@@ -588,7 +588,7 @@ def csr_gs_schedule(A, x, b, sched, sweeps=1):
     ell = _gs_ell(A, sched)
     if ell is not None and ell[1] is not None:
         _key, K, rows, start, ln, cols, total = ell
-        check(_lib.lib().lmg_csr_gs_schedule_ell(_p(A.vals), _p(x), _p(b), _p(rows), _p(start), _p(ln), _p(cols),
+        check(_lib.lib().lmg_csr_gs_schedule_ell(x.numel(), _p(A.vals), _p(x), _p(b), _p(rows), _p(start), _p(ln), _p(cols),
                                                  K, total, _p(sched.d_ptr), sched.nsets, int(sweeps), _s()),
               "lmg_csr_gs_schedule_ell")
         return

@@ -81,7 +81,8 @@ def _worker(rank, world, port, m, levels, replicate_below, steps, halo_depth, ou
                           (2, 48, 3, 1, 3, 5),          # fine level one layer short (its restriction reads two hops away)
                           (2, 48, 3, 1, 4, 5),          # deeper cycle than the halo: exchange before every sweep
                           (3, 40, 4, 300, 2, 1),        # classic one-layer halo (empty ghost rows)
-                          (4, 64, 4, 500, 3, 6)])       # four ranks, V(3,3) like the bench
+                          (4, 64, 4, 500, 3, 6),        # four ranks, V(3,3) like the bench
+                          (8, 128, 4, 2000, 3, 6)])     # the bench's N = 8 topology in small: two distributed levels
 def test_distributed_vcycle_matches_single_process(tmp_path, world, m, levels, replicate_below, steps, halo_depth):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, m, levels, replicate_below, steps, halo_depth, str(tmp_path)),

@@ -181,7 +181,7 @@ def main():
         from learnmultigrid_amd.dist import DistributedVCycle
         t0 = time.perf_counter()
         D = DistributedVCycle.from_problem(A, hier, dev, grid_side=m + 1,
-                                           halo_depth=int(os.environ.get("LMG_HALO_DEPTH", nu + 3)))
+                                           halo_depth=int(os.environ.get("LMG_HALO_DEPTH", 2 * nu + 2)))
         setup_s = time.perf_counter() - t0
         D.set_rhs(rhs)
         D.use_tail_graph = not args.no_graph

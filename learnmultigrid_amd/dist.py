@@ -17,17 +17,21 @@ point-to-point xGMI links):
   * One halo exchange = a pack kernel (lmg_gather) + one grouped batch of
     isend / irecv (<= 2 neighbours).  Messages are latency-bound, not xGMI-bandwidth-bound,
     so the cycle is organised to need FEW of them: the ghost set of a level reaches
-    `halo_depth` (default 6 = nu + 1 + the two hops the 9-point restriction of a 5-point
-    operator reads, for nu = 3) matrix hops beyond the owned block and the local
-    operator A_l carries the real rows of all but the outermost ghost layer.  After one
-    exchange of x every sweep on the whole local block is exact one layer less deep than the
-    previous one, so nu sweeps, the residual on the owned rows AND on the first ghost layer
-    (which the restriction reads) need no further message: 3 exchanges per level and cycle
-    (x before pre-smoothing -- b on the coarse levels, whose iterate starts from zero --, the
-    coarse correction before prolongation, x before post-smoothing) instead of 2 nu + 3.
-    The redundant work is halo_depth grid lines per neighbour (197 KB messages on the fine
-    level of cfg#4).  Levels whose restriction reads further than the halo allows, and cycles
-    with more sweeps, fall back to one exchange per use on that level.
+    `halo_depth` (default 8) matrix hops beyond the owned block and the local operators A_l
+    and P_l carry the real rows of all ghost layers but the outermost.  After one exchange of
+    x every sweep on the whole local block is exact one layer less deep than the previous
+    one, so nu sweeps, the residual on the owned rows AND on the ghost layers the restriction
+    reads (two hops of a 5-point operator for a 9-point restriction) need no further message
+    (halo_depth >= nu + 3).  The correction is prolongated on the ghost layers as well, so the
+    corrected iterate is still exact on halo_depth - nu >= nu layers and post-smoothing needs
+    no message either (halo_depth >= 2 nu); and what post-smoothing leaves exact on a coarse
+    level (halo_depth - 2 nu layers) is enough for the finer level's prolongation when
+    halo_depth >= 2 nu + 2.  With nu = 3 and depth 8 that is ONE exchange per distributed level
+    and cycle -- x on the fine level, b on the coarse ones (their iterate starts from zero) --
+    instead of 2 nu + 2; cfg#4: 2 instead of 16.  The redundant work is halo_depth grid lines
+    per neighbour (262 KB messages on the fine level of cfg#4).  All depths are measured at
+    setup from the hop distances of the columns of R and P and agreed over the ranks; levels
+    or cycles that need more than the halo offers fall back, per level, to one exchange per use.
   * Levels with fewer than `replicate_below` rows (default 2 M: below that a halo
     exchange costs more than computing the whole level redundantly) are NOT distributed: the restricted
     residual is all-gathered once per cycle and every rank runs the rest of the cycle
@@ -106,7 +110,7 @@ class _DLevel:
 
 class DistributedVCycle:
     def __init__(self, full, device, ops_mod=None, grid_side=None, replicate_below=2_000_000,
-                 group=None, halo_depth=6):
+                 group=None, halo_depth=8):
         """full: a replicated hierarchy (learnmultigrid_amd.hierarchy.Hierarchy or anything
         with the same .levels[l].A/.P/.R, .coarse_solve(), .cycle())."""
         if ops_mod is None:
@@ -164,7 +168,9 @@ class DistributedVCycle:
             clo, chi = self.bounds[l + 1][self.rank], self.bounds[l + 1][self.rank + 1]
             lev = full.levels[l]
             raw.append({"A": _rows(lev.A, lo, hi), "P": _rows(lev.P, lo, hi), "R": _rows(lev.R, clo, chi)})
-        ghosts, real_ghosts, r_need = [], [], []
+        # The prolongation is applied on every ghost layer that carries real rows too, so that the
+        # corrected iterate needs no exchange before post-smoothing (see cycle()).
+        ghosts, real_ghosts, r_need, p_ghost_rows, layers_all = [], [], [], [], []
         for l in range(self.n_dist):
             lo, hi = self.bounds[l][self.rank], self.bounds[l][self.rank + 1]
             A_l = full.levels[l].A
@@ -203,16 +209,48 @@ class DistributedVCycle:
                         lay = torch.where(fr[pos] == rc, torch.full_like(lay, k), lay)
                 need = int(lay.max())
             r_need.append(need)
+            p_ghost_rows.append(real)                  # ghost rows of this level that carry real P rows
+            layers_all.append(layers)
             extra = [raw[l]["R"][1]]
             if l > 0:
                 extra.append(raw[l - 1]["P"][1])
+                # ... and what the P rows of the finer level's inner ghost layers reference
+                extra.append(_gather_rows(full.levels[l - 1].P, p_ghost_rows[l - 1])[1])
             known = torch.unique(torch.cat([known, outside(torch.cat(extra), known)]))
             ghosts.append(known)                       # sorted
             real_ghosts.append(real)
+        # p_need[l][k]: deepest ghost layer of level l+1 that the P rows of the level-l ghost layers
+        # <= k read (0: owned coarse rows only; the replicated level below the last distributed one
+        # is complete on every rank)
+        p_need = []
+        for l in range(self.n_dist):
+            need_k = [0] * (self.halo_depth + 1)
+            if l + 1 < self.n_dist:
+                clo, chi = self.bounds[l + 1][self.rank], self.bounds[l + 1][self.rank + 1]
+                worst = 0
+                for k in range(0, self.halo_depth):
+                    rows_k = None if k == 0 else (layers_all[l][k - 1] if k - 1 < len(layers_all[l]) else None)
+                    cols = raw[l]["P"][1] if k == 0 else (
+                        _gather_rows(full.levels[l].P, rows_k)[1] if rows_k is not None and rows_k.numel() else None)
+                    if cols is not None and cols.numel():
+                        c = torch.unique(cols.long())
+                        c = c[(c < clo) | (c >= chi)]
+                        if c.numel():
+                            lay = torch.full((c.numel(),), 1 << 20, dtype=torch.long, device=c.device)
+                            for kk, fr in enumerate(layers_all[l + 1], 1):
+                                if fr.numel():
+                                    pos = torch.searchsorted(fr, c).clamp(max=fr.numel() - 1)
+                                    lay = torch.where(fr[pos] == c, torch.full_like(lay, kk), lay)
+                            worst = max(worst, int(lay.max()))
+                    need_k[k] = worst
+                need_k[self.halo_depth] = worst
+            p_need.append(need_k)
         gathered = [None] * self.world
-        dist.all_gather_object(gathered, [g.cpu().numpy() for g in ghosts] + [r_need], group=group)
+        dist.all_gather_object(gathered, [g.cpu().numpy() for g in ghosts] + [r_need, p_need], group=group)
         # every rank must take the same branch of the cycle (the exchanges are collective)
-        self.r_need = [max(g[-1][l] for g in gathered) for l in range(self.n_dist)]
+        self.r_need = [max(g[-2][l] for g in gathered) for l in range(self.n_dist)]
+        self.p_need = [[max(g[-1][l][k] for g in gathered) for k in range(self.halo_depth + 1)]
+                       for l in range(self.n_dist)]
         self.dl = []
         for l in range(self.n_dist):
             d = _DLevel()
@@ -284,18 +322,40 @@ class DistributedVCycle:
             d.dinv = self.ops.csr_inverse_diagonal(d.A)
             rp, ci, va = raw[l]["R"]                      # rows: level l+1, columns: level l
             rp_p, ci_p, va_p = raw[l]["P"]                # rows: level l,   columns: level l+1
+            # P rows: owned rows + the inner ghost layers (real), other ghost rows empty
+            P_l = full.levels[l].P
+            pg = p_ghost_rows[l]
+            pp_rp, pp_ci, pp_va = [], [], []
+            for gset in (d.ghost_lo, None, d.ghost_hi):
+                if gset is None:
+                    pp_rp.append((rp_p[1:] - rp_p[:-1]).long())
+                    pp_ci.append(ci_p)
+                    pp_va.append(va_p)
+                    continue
+                if gset.numel() and pg.numel():
+                    pos = torch.searchsorted(pg, gset).clamp(max=pg.numel() - 1)
+                    is_real = pg[pos] == gset
+                else:
+                    is_real = torch.zeros(gset.numel(), dtype=torch.bool, device=gset.device)
+                cnt, gci, gva = _gather_rows(P_l, gset[is_real])
+                full_cnt = torch.zeros(gset.numel(), dtype=torch.long, device=gset.device)
+                full_cnt[is_real] = cnt
+                pp_rp.append(full_cnt)
+                pp_ci.append(gci)
+                pp_va.append(gva)
+            rp_ploc = torch.zeros(d.n_tot + 1, dtype=I32, device=va.device)
+            rp_ploc[1:] = torch.cumsum(torch.cat(pp_rp), 0).to(I32)
+            ci_ploc, va_ploc = torch.cat(pp_ci), torch.cat(pp_va).contiguous()
             if l + 1 < self.n_dist:
                 nxt = self.dl[l + 1]
                 d.R = DeviceCSR(nxt.embed_rows(rp), d.to_local(ci).to(I32).contiguous(), va.contiguous(),
                                 (nxt.n_tot, d.n_tot))
-                d.P = DeviceCSR(d.embed_rows(rp_p), nxt.to_local(ci_p).to(I32).contiguous(),
-                                va_p.contiguous(), (d.n_tot, nxt.n_tot))
+                d.P = DeviceCSR(rp_ploc, nxt.to_local(ci_ploc).to(I32).contiguous(), va_ploc, (d.n_tot, nxt.n_tot))
             else:                                         # next level is replicated on every rank
                 nrows = self.bounds[l + 1][self.rank + 1] - self.bounds[l + 1][self.rank]
                 d.R = DeviceCSR(rp.contiguous(), d.to_local(ci).to(I32).contiguous(), va.contiguous(),
                                 (nrows, d.n_tot))
-                d.P = DeviceCSR(d.embed_rows(rp_p), ci_p.contiguous(), va_p.contiguous(),
-                                (d.n_tot, full.levels[l + 1].n))
+                d.P = DeviceCSR(rp_ploc, ci_ploc.contiguous(), va_ploc, (d.n_tot, full.levels[l + 1].n))
         if getattr(full, "use_packed", False):
             for d in self.dl:
                 for M in (d.A, d.R, d.P):
@@ -381,13 +441,14 @@ class DistributedVCycle:
         return np.concatenate(parts)
 
     # ---- the cycle ---------------------------------------------------------------------------------------
-    def _smooth(self, d, steps, omega, x_is_zero=False, deep=False):
+    def _smooth(self, d, steps, omega, x_is_zero=False, deep=False, exchanged=False):
         """`steps` Jacobi sweeps on the whole local block.  deep: the ghosts of x (of b when the
-        iterate starts from zero) are exchanged ONCE; sweep k is then exact up to ghost layer
-        halo_depth - k, which is all the next sweep needs.  Otherwise one exchange per sweep."""
+        iterate starts from zero) are exchanged ONCE (not at all when the caller knows they are
+        exact: `exchanged`); sweep k is then exact up to ghost layer halo_depth - k, which is all
+        the next sweep needs.  Otherwise one exchange per sweep."""
         o = self.ops
         if x_is_zero and steps > 0:
-            if deep:
+            if deep and not exchanged:
                 self.exchange(d, d.b)
             # first sweep from zeros: x = omega * (D^-1 b), no halo of x needed
             o.vmul(omega, d.dinv, d.b, d.tmp)
@@ -395,7 +456,7 @@ class DistributedVCycle:
             steps -= 1
         elif x_is_zero:
             o.zero(d.x)
-        elif deep:
+        elif deep and not exchanged:
             self.exchange(d, d.x)
         for _ in range(steps):
             if not deep:
@@ -404,25 +465,38 @@ class DistributedVCycle:
             d.x, d.tmp = d.tmp, d.x
 
     def cycle(self, smoother, steps, omega=1.0, l=0, x_is_zero=False):
+        """One V-cycle from level l down.  Returns the number of ghost layers on which this level's
+        iterate is exact afterwards (what the caller may prolongate from without a message)."""
         if smoother != "Jacobi":
             raise ValueError("the distributed V-cycle supports the Jacobi smoother only "
                              "(lexicographic Gauss-Seidel is sequential across ranks)")
         o = self.ops
         d = self.dl[l]
+        D = self.halo_depth
         # nu sweeps + the residual on the ghost layers the restriction reads consume nu + 1 + r_need
         # layers of one exchange; otherwise (deeper cycles, wide transfers) exchange before every use
-        deep = steps >= 1 and steps + 1 + max(1, self.r_need[l]) <= self.halo_depth
+        deep = steps >= 1 and steps + 1 + max(1, self.r_need[l]) <= D
         self._smooth(d, steps, omega, x_is_zero, deep)
         if not deep:
             self.exchange(d, d.x)
         o.csr_residual_norm2(d.A, d.x, d.b, d.r, None, None)
         if not deep:
             self.exchange(d, d.r)
+        # The prolongation is applied on the ghost layers too (real P rows there).  The iterate is
+        # exact on D - steps layers before the correction; if the correction is exact on V >= steps
+        # of them, post-smoothing needs no message and leaves V - steps exact layers behind.
+        want_local = deep and 2 * steps <= D
+        V = 0
         if l + 1 < self.n_dist:
             nxt = self.dl[l + 1]
             o.csr_spmv(d.R, d.r, nxt.b, 1.0, 0.0)
-            self.cycle(smoother, steps, omega, l + 1, x_is_zero=True)
-            self.exchange(nxt, nxt.x)
+            v_next = self.cycle(smoother, steps, omega, l + 1, x_is_zero=True)
+            if want_local:
+                # largest V whose P rows only read coarse ghosts that are already exact
+                V = max([k for k in range(steps, D - steps + 1) if self.p_need[l][k] <= v_next], default=0)
+            if V == 0:
+                self.exchange(nxt, nxt.x)
+                V = D - steps if want_local else 0
             o.csr_spmv(d.P, nxt.x, d.x, 1.0, 1.0)
         else:
             fl = self.full.levels[l + 1]
@@ -435,8 +509,11 @@ class DistributedVCycle:
                 dist.all_gather_into_tensor(self.ag_recv, self.ag_send, group=self.group)
             o.gather(self.ag_index, self.ag_recv, fl.b)
             self._replicated_tail(smoother, steps, omega, l + 1)
-            o.csr_spmv(d.P, fl.x, d.x, 1.0, 1.0)
-        self._smooth(d, steps, omega, False, deep)
+            o.csr_spmv(d.P, fl.x, d.x, 1.0, 1.0)      # the replicated correction is complete on every rank
+            V = D - steps if want_local else 0
+        local_up = want_local and V >= steps
+        self._smooth(d, steps, omega, False, deep, exchanged=local_up)
+        return V - steps if local_up else 0
 
     def _replicated_tail(self, smoother, steps, omega, l):
         """The part of the cycle below the distributed levels: purely local work on the

@@ -77,12 +77,13 @@ def _worker(rank, world, port, m, levels, replicate_below, steps, halo_depth, ou
 
 @pytest.mark.parametrize("world,m,levels,replicate_below,steps,halo_depth",
                          [(2, 32, 4, 200, 2, 6), (2, 48, 3, 1, 2, 6), (3, 40, 4, 300, 2, 6),
-                          (2, 48, 3, 1, 3, 6),          # nu + 3 = halo depth: still three exchanges per level
+                          (2, 48, 3, 1, 3, 8),          # 2 nu + 2 = halo depth: one exchange per level
+                          (2, 48, 3, 1, 3, 6),          # nu + 3 = halo depth: the coarse corrections travel too
                           (2, 48, 3, 1, 3, 5),          # fine level one layer short (its restriction reads two hops away)
                           (2, 48, 3, 1, 4, 5),          # deeper cycle than the halo: exchange before every sweep
                           (3, 40, 4, 300, 2, 1),        # classic one-layer halo (empty ghost rows)
-                          (4, 64, 4, 500, 3, 6),        # four ranks, V(3,3) like the bench
-                          (8, 128, 4, 2000, 3, 6)])     # the bench's N = 8 topology in small: two distributed levels
+                          (4, 64, 4, 500, 3, 8),        # four ranks, V(3,3) like the bench
+                          (8, 128, 4, 2000, 3, 8)])     # the bench's N = 8 topology in small: two distributed levels
 def test_distributed_vcycle_matches_single_process(tmp_path, world, m, levels, replicate_below, steps, halo_depth):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, m, levels, replicate_below, steps, halo_depth, str(tmp_path)),
@@ -94,13 +95,21 @@ def test_distributed_vcycle_matches_single_process(tmp_path, world, m, levels, r
         assert info["contracting"], info
         assert info["cuts_on_lines"], info
         assert info["n_dist"] >= 1
-        # number of halo exchanges of one cycle: 3 per distributed level with the deep halo (the
-        # deepest one has no distributed level below it to fetch a correction from: 2), against
-        # 2 nu + 2 (+1) with one exchange per use
+        # number of halo exchanges of one cycle with the deep halo: x (b on coarse levels) before
+        # pre-smoothing and the coarse correction before prolongation (none below the deepest
+        # distributed level) -- 2 per level minus 1; one more per level when the halo is too thin to
+        # apply the correction on the ghost layers; 2 nu + 2 (+1) with one exchange per use
         nd = info["n_dist"]
         deep = [steps + 1 + max(1, rn) <= halo_depth for rn in info["r_need"]]
+        local_up = 2 * steps <= halo_depth            # the correction is applied on the ghost layers too
         if all(deep):
-            assert all(c == 3 * nd - 1 for c in info["exchanges_per_cycle"]), info
+            # one message per level; one more per level (but the deepest) when post-smoothing leaves
+            # too few exact layers for the finer level's prolongation; a third one when the halo is
+            # too thin to keep the corrected iterate exact on nu layers
+            lo_n, hi_n = nd, (2 if local_up else 3) * nd - 1
+            assert all(lo_n <= c <= hi_n for c in info["exchanges_per_cycle"]), info
+            if halo_depth >= 2 * steps + 2:
+                assert all(c == nd for c in info["exchanges_per_cycle"]), info
         elif not any(deep):
             assert all(c >= (2 * steps + 1) * nd for c in info["exchanges_per_cycle"]), info
         # the 9-point restriction of a 5-point operator reads residuals two matrix hops away

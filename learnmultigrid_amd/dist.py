@@ -65,25 +65,34 @@ def block_bounds(n_units, world):
 
 
 def _rows(M, lo, hi):
-    """Rows [lo, hi) of a CSR held in tensors: (rowptr_local, colidx_global, vals)."""
+    """Rows [lo, hi) of a CSR held in tensors: (rowptr_local, colidx_global, vals, source) --
+    `source` says where the values came from (see _take)."""
     rp = M.rowptr[lo:hi + 1].long()
     s, e = int(rp[0]), int(rp[-1])
-    return (rp - s).to(I32), M.colidx[s:e], M.vals[s:e]
+    return (rp - s).to(I32), M.colidx[s:e], M.vals[s:e], ("slice", s, e)
 
 
-def _gather_rows(M, rows):
+def _gather_rows(M, rows, with_source=False):
     """Entries of the given rows (int64 tensor) of a CSR in tensors: (counts, colidx, vals),
     rows in the given order, entries in storage order."""
     if rows.numel() == 0:
-        return (torch.zeros(0, dtype=torch.long, device=M.vals.device), M.colidx[:0], M.vals[:0])
+        out = (torch.zeros(0, dtype=torch.long, device=M.vals.device), M.colidx[:0], M.vals[:0])
+        return out + (("slice", 0, 0),) if with_source else out
     start = M.rowptr[rows].long()
     cnt = M.rowptr[rows + 1].long() - start
     tot = int(cnt.sum())
     if tot == 0:
-        return cnt, M.colidx[:0], M.vals[:0]
+        out = (cnt, M.colidx[:0], M.vals[:0])
+        return out + (("slice", 0, 0),) if with_source else out
     first = torch.cumsum(cnt, 0) - cnt                       # position of every row's first entry
     idx = torch.repeat_interleave(start - first, cnt) + torch.arange(tot, device=M.vals.device)
-    return cnt, M.colidx[idx], M.vals[idx]
+    out = (cnt, M.colidx[idx], M.vals[idx])
+    return out + (("index", idx),) if with_source else out
+
+
+def _take(vals, sources):
+    """Values of a local operator from the replicated one, by the sources recorded when it was cut."""
+    return torch.cat([vals[src[1]:src[2]] if src[0] == "slice" else vals[src[1]] for src in sources])
 
 
 class _DLevel:
@@ -292,27 +301,29 @@ class DistributedVCycle:
         # ---- local operators in the level layouts -------------------------------------------------
         for l in range(self.n_dist):
             d = self.dl[l]
-            rp, ci, va = raw[l]["A"]
+            rp, ci, va, src_own = raw[l]["A"]
             A_l = full.levels[l].A
             rg = real_ghosts[l]
-            parts_rp, parts_ci, parts_va = [], [], []
+            parts_rp, parts_ci, parts_va, d.A_src = [], [], [], []
             for gset in (d.ghost_lo, None, d.ghost_hi):
                 if gset is None:
                     parts_rp.append((rp[1:] - rp[:-1]).long())
                     parts_ci.append(ci)
                     parts_va.append(va)
+                    d.A_src.append(src_own)
                     continue
                 if gset.numel() and rg.numel():
                     pos = torch.searchsorted(rg, gset).clamp(max=rg.numel() - 1)
                     is_real = rg[pos] == gset
                 else:
                     is_real = torch.zeros(gset.numel(), dtype=torch.bool, device=gset.device)
-                cnt, gci, gva = _gather_rows(A_l, gset[is_real])
+                cnt, gci, gva, gsrc = _gather_rows(A_l, gset[is_real], with_source=True)
                 full_cnt = torch.zeros(gset.numel(), dtype=torch.long, device=gset.device)
                 full_cnt[is_real] = cnt
                 parts_rp.append(full_cnt)
                 parts_ci.append(gci)
                 parts_va.append(gva)
+                d.A_src.append(gsrc)
             counts = torch.cat(parts_rp)
             rp_loc = torch.zeros(d.n_tot + 1, dtype=I32, device=va.device)
             rp_loc[1:] = torch.cumsum(counts, 0).to(I32)
@@ -320,29 +331,32 @@ class DistributedVCycle:
                             torch.cat(parts_va).contiguous(), (d.n_tot, d.n_tot))
             d.rows_global = torch.cat([d.ghost_lo, torch.arange(d.lo, d.hi, device=va.device), d.ghost_hi])
             d.dinv = self.ops.csr_inverse_diagonal(d.A)
-            rp, ci, va = raw[l]["R"]                      # rows: level l+1, columns: level l
-            rp_p, ci_p, va_p = raw[l]["P"]                # rows: level l,   columns: level l+1
+            rp, ci, va, src_r = raw[l]["R"]               # rows: level l+1, columns: level l
+            rp_p, ci_p, va_p, src_p = raw[l]["P"]         # rows: level l,   columns: level l+1
+            d.R_src = [src_r]
             # P rows: owned rows + the inner ghost layers (real), other ghost rows empty
             P_l = full.levels[l].P
             pg = p_ghost_rows[l]
-            pp_rp, pp_ci, pp_va = [], [], []
+            pp_rp, pp_ci, pp_va, d.P_src = [], [], [], []
             for gset in (d.ghost_lo, None, d.ghost_hi):
                 if gset is None:
                     pp_rp.append((rp_p[1:] - rp_p[:-1]).long())
                     pp_ci.append(ci_p)
                     pp_va.append(va_p)
+                    d.P_src.append(src_p)
                     continue
                 if gset.numel() and pg.numel():
                     pos = torch.searchsorted(pg, gset).clamp(max=pg.numel() - 1)
                     is_real = pg[pos] == gset
                 else:
                     is_real = torch.zeros(gset.numel(), dtype=torch.bool, device=gset.device)
-                cnt, gci, gva = _gather_rows(P_l, gset[is_real])
+                cnt, gci, gva, gsrc = _gather_rows(P_l, gset[is_real], with_source=True)
                 full_cnt = torch.zeros(gset.numel(), dtype=torch.long, device=gset.device)
                 full_cnt[is_real] = cnt
                 pp_rp.append(full_cnt)
                 pp_ci.append(gci)
                 pp_va.append(gva)
+                d.P_src.append(gsrc)
             rp_ploc = torch.zeros(d.n_tot + 1, dtype=I32, device=va.device)
             rp_ploc[1:] = torch.cumsum(torch.cat(pp_rp), 0).to(I32)
             ci_ploc, va_ploc = torch.cat(pp_ci), torch.cat(pp_va).contiguous()
@@ -540,6 +554,21 @@ class DistributedVCycle:
                 raise RuntimeError("ping-pong buffers did not return to their slots")
             self._tail_graphs[key] = g
         g.launch()
+
+    def rebuild_numeric(self, new_vals):
+        """Galerkin rebuild after the VALUES of the fine matrix changed (config #5).  The numeric
+        SpGEMM passes run on the replicated hierarchy of every rank (no communication); the local
+        operators then take their values again from where they were cut, and their lossless twins
+        are refreshed."""
+        self.full.rebuild_numeric(new_vals)
+        for l, d in enumerate(self.dl):
+            lev = self.full.levels[l]
+            for local, replicated, src in ((d.A, lev.A, d.A_src), (d.P, lev.P, d.P_src), (d.R, lev.R, d.R_src)):
+                if local.nnz:
+                    local.vals.copy_(_take(replicated.vals, src))
+                    local.repack_values()
+            d.dinv = self.ops.csr_inverse_diagonal(d.A)
+        self._tail_graphs = {}           # the replicated tail's graph holds pointers of the old twins
 
     def residual_norm(self):
         """||b - A x||_2 over all ranks: local fused sum of squares + all-reduce of 8 bytes."""

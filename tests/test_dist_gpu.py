@@ -94,6 +94,14 @@ def _gpu_worker(rank, world, port, out_dir, transfer="geometric"):
             for _ in range(3):
                 D.cycle("Jacobi", 3, 0.8)
                 norms.append(D.residual_norm())
+            if transfer == "learned":
+                # config #5: new coefficients on the same pattern, numeric Galerkin rebuild, go on
+                rng = np.random.default_rng(77)
+                new_vals = torch.from_numpy(np.ascontiguousarray(A.tocsr().data * (1.0 + 0.2 * rng.random(A.nnz)))).to("cuda:0")
+                D.rebuild_numeric(new_vals)
+                for _ in range(2):
+                    D.cycle("Jacobi", 3, 0.8)
+                    norms.append(D.residual_norm())
         x = D.gather_solution()
         H = Hierarchy(A, hier, "cuda:0")
         H.levels[0].b.copy_(torch.from_numpy(rhs.ravel().copy()).to("cuda:0"))
@@ -102,10 +110,15 @@ def _gpu_worker(rank, world, port, out_dir, transfer="geometric"):
             for _ in range(3):
                 H.cycle("Jacobi", 3, 0.8)
                 ref.append(H.residual_norm())
+            if transfer == "learned":
+                H.rebuild_numeric(new_vals)
+                for _ in range(2):
+                    H.cycle("Jacobi", 3, 0.8)
+                    ref.append(H.residual_norm())
             xr = H.levels[0].x.cpu().numpy()
         ok = bool(np.array_equal(x, xr)) and bool(np.allclose(norms, ref, rtol=1e-13, atol=0))
         np.save(os.path.join(out_dir, "ok_%d.npy" % rank),
-                np.array([ok, norms[-1] < (1e-3 if transfer == "geometric" else 0.9) * norms[0]]))
+                np.array([ok, norms[3] < (1e-3 if transfer == "geometric" else 0.9) * norms[0]]))
     finally:
         dist.destroy_process_group()
 

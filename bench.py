@@ -153,6 +153,8 @@ def main():
         ops.set_packed_enabled(False)
     if args.no_patterns:
         ops.set_patterns_enabled(False)
+    if os.environ.get("LMG_RPAT_NT_ROWS"):
+        ops.tune_set("rpat_variant", int(os.environ["LMG_RPAT_NT_ROWS"]))     # tuning knob (>= 1000: threshold)
 
     m, levels, nu = args.size, args.levels, args.nu
     if args.problem == "poisson":

@@ -235,12 +235,12 @@ int launch_nt(RArgs a, hipStream_t st)
     return a.tiles;
 }
 
-constexpr int kNontemporalRows = 1 << 23;
+int g_rpat_nt_rows = 1 << 23;      // rows from which the id / b / out streams bypass the caches (tunable)
 
 template <int MODE, int JU, int kRpt>
 int launch_one(RArgs a, hipStream_t st)
 {
-    return a.n >= kNontemporalRows ? launch_nt<MODE, JU, kRpt, true>(a, st) : launch_nt<MODE, JU, kRpt, false>(a, st);
+    return a.n >= g_rpat_nt_rows ? launch_nt<MODE, JU, kRpt, true>(a, st) : launch_nt<MODE, JU, kRpt, false>(a, st);
 }
 
 template <int MODE>
@@ -325,6 +325,7 @@ __global__ void __launch_bounds__(256) pattern_verify_kernel(int64_t n, int64_t 
 
 int lmg_rpat_tune_set(int v)
 {
+    if (v >= 1000) { g_rpat_nt_rows = v; return LMG_OK; }      // >= 1000: nontemporal threshold in rows
     if (v < 0 || v > 4) return LMG_ERR_ARG;
     g_rpat_variant = v;
     return LMG_OK;

@@ -47,9 +47,13 @@ struct RArgs {
 // NT: the streams without reuse (pattern ids, b, out) bypass the caches.  It pays when the vectors do
 // not fit the 256 MB Infinity Cache anyway (cfg#4 fine level: -8 %) and costs 20 % when they do
 // (2049^2), so the launcher turns it on from 8 M rows.
+#ifndef LMG_RPAT_NT_MODE
+#define LMG_RPAT_NT_MODE 3          // bit 0: nontemporal loads of ids / b, bit 1: nontemporal stores of out
+#endif
 template <int MODE, int JU, int kRpt, bool NT>
 __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
 {
+    constexpr bool NTL = NT && (LMG_RPAT_NT_MODE & 1), NTS = NT && (LMG_RPAT_NT_MODE & 2);
     constexpr int kTileRows = kBlock * kRpt;
     __shared__ int s_ptr[kMaxPat + 1];
     __shared__ int s_off[kMaxEnt];
@@ -94,8 +98,8 @@ __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
 #pragma unroll
         for (int k = 0; k < kRpt; ++k) {
             const int r = tl * kTileRows + k * kBlock + t;
-            pat[k] = r < a.n ? (int)(NT ? __builtin_nontemporal_load(a.pid + r) : a.pid[r]) : 0;
-            bv[k] = (MODE != MODE_SPMV && r < a.n) ? (NT ? __builtin_nontemporal_load(a.b + r) : a.b[r]) : 0.0;
+            pat[k] = r < a.n ? (int)(NTL ? __builtin_nontemporal_load(a.pid + r) : a.pid[r]) : 0;
+            bv[k] = (MODE != MODE_SPMV && r < a.n) ? (NTL ? __builtin_nontemporal_load(a.b + r) : a.b[r]) : 0.0;
         }
     };
     auto process = [&](int tile, const int (&pat)[kRpt], const double (&bv)[kRpt]) {
@@ -155,7 +159,7 @@ __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
                 if (MODE == MODE_RESIDUAL) {
                     const double r = bv[k] - acc[k];
                     if (a.out) {
-                        if (NT) __builtin_nontemporal_store(r, a.out + row[k]);
+                        if (NTS) __builtin_nontemporal_store(r, a.out + row[k]);
                         else a.out[row[k]] = r;
                     }
                     local += r * r;
@@ -163,7 +167,7 @@ __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
                     const double r = bv[k] - acc[k];
                     if (s_diag[pat[k]] != 0.0) {
                         const double o = xi[k] + a.alpha * (s_rdiag[pat[k]] * r);
-                        if (NT) __builtin_nontemporal_store(o, a.out + row[k]);
+                        if (NTS) __builtin_nontemporal_store(o, a.out + row[k]);
                         else a.out[row[k]] = o;
                     }
                     else a.out[row[k]] = a.x[row[k]];
@@ -171,7 +175,7 @@ __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
                     double s = acc[k];
                     if (a.alpha != 1.0) s = a.alpha * s;
                     if (a.beta == 0.0) {
-                        if (NT) __builtin_nontemporal_store(s, a.out + row[k]);
+                        if (NTS) __builtin_nontemporal_store(s, a.out + row[k]);
                         else a.out[row[k]] = s;
                     } else if (a.beta == 1.0) a.out[row[k]] = a.out[row[k]] + s;
                     else a.out[row[k]] = a.beta * a.out[row[k]] + s;

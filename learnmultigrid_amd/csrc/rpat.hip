@@ -329,12 +329,21 @@ __global__ void __launch_bounds__(256) pattern_verify_kernel(int64_t n, int64_t 
 
 int lmg_rpat_tune_set(int v)
 {
-    if (v >= 1000) { g_rpat_nt_rows = v; return LMG_OK; }      // >= 1000: nontemporal threshold in rows
+    if (v >= 1000) { g_rpat_nt_rows = v; return LMG_OK; }      // >= 1000: nontemporal threshold in rows (legacy spelling)
     if (v < 0 || v > 4) return LMG_ERR_ARG;
     g_rpat_variant = v;
     return LMG_OK;
 }
 int lmg_rpat_tune_get(void) { return g_rpat_variant; }
+// "rpat_nt_rows": rows from which the streams without reuse bypass the caches (1 = always, the parity
+// tests force the nontemporal instantiations on small matrices this way)
+int lmg_rpat_nt_set(int v)
+{
+    if (v < 1) return LMG_ERR_ARG;
+    g_rpat_nt_rows = v;
+    return LMG_OK;
+}
+int lmg_rpat_nt_get(void) { return g_rpat_nt_rows; }
 
 extern "C" {
 

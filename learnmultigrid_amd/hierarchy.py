@@ -152,7 +152,14 @@ class Hierarchy:
                 lev.host_pattern = (lev.A.rowptr.cpu().numpy(), lev.A.colidx.cpu().numpy())
             rp, ci = lev.host_pattern
             pat = sp.csr_matrix((np.ones(ci.size, dtype=np.int8), ci, rp), shape=lev.A.shape)
-            lev.gs_sched[kind] = self.ops.build_gs_schedule(pat, kind, self.device)
+            sched = self.ops.build_gs_schedule(pat, kind, self.device)
+            # the schedule-ordered pattern copy of the one-workgroup executor is built HERE, eagerly:
+            # it allocates and reads sizes back to the host, which must never happen while a
+            # hipGraph is being captured (captured_cycle only calls gs_schedule before the capture)
+            prep = getattr(self.ops, "gs_prepare", None)
+            if prep is not None:
+                prep(lev.A, sched)
+            lev.gs_sched[kind] = sched
         return lev.gs_sched[kind]
 
     # ------------------------------------------------------------------ solve ----------

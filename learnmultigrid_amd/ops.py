@@ -583,6 +583,12 @@ def _gs_ell(A, sched):
     return sched.ell
 
 
+def gs_prepare(A, sched):
+    """Everything csr_gs_schedule would otherwise build lazily on its first call (allocations, a
+    device -> host size read): call it at setup so that the sweep itself is capture-safe."""
+    _gs_ell(A, sched)
+
+
 def csr_gs_schedule(A, x, b, sched, sweeps=1):
     _vec_ok(x, b)
     ell = _gs_ell(A, sched)

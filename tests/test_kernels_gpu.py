@@ -755,7 +755,10 @@ def rpat_case(name):
 @pytest.mark.parametrize("name", ["poisson2d_129", "poisson1d", "galerkin_9pt", "galerkin_l2_rounded",
                                   "with_empty_and_diagless_rows", "duplicate_diagonal"])
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
-def test_row_pattern_sweeps_bit_exact(name, variant):
+@pytest.mark.parametrize("nt", [False, True], ids=["cached", "nontemporal"])
+def test_row_pattern_sweeps_bit_exact(name, variant, nt):
+    """nt=True forces the NT = true instantiations (nontemporal id / b loads and out stores) that the
+    launcher otherwise only picks from 8 M rows on -- the ones the headline bench times."""
     A = rpat_case(name)
     n = A.shape[0]
     keys, ids = _numpy_row_patterns(A)
@@ -799,8 +802,13 @@ def test_row_pattern_sweeps_bit_exact(name, variant):
             K.lib().orc_csr_jacobi(n, rp_, ci_, va_, x_, b_, om, o)
             return o
     Ac = A
+    nt_default = ops.tune_get("rpat_nt_rows")
+    assert nt_default == 1 << 23
     try:
         ops.tune_set("rpat_variant", variant)
+        if nt:
+            ops.tune_set("rpat_nt_rows", 1)
+            assert ops.tune_get("rpat_nt_rows") == 1
         for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (-0.5, 2.0)):
             y = dev(y0.copy())
             ops.csr_spmv(dA, dev(x), y, alpha, beta)
@@ -827,6 +835,47 @@ def test_row_pattern_sweeps_bit_exact(name, variant):
     finally:
         ops.set_packed_enabled(True)
         ops.tune_set("rpat_variant", 0)
+        ops.tune_set("rpat_nt_rows", nt_default)
+
+
+def test_row_pattern_sweeps_full_size_4097_bit_exact_vs_oracle():
+    """The instantiations the headline bench times -- rpat_sweep_kernel<JACOBI|RESIDUAL, 5, 2, NT = true>
+    on the 16.8 M-row fine level of cfg#4 -- against oracle/lmg_oracle.c, bitwise, at full size."""
+    A = K.as_csr(P.poisson_2d_structured(4096)[0])
+    n = A.shape[0]
+    assert n == 4097 * 4097 and n >= ops.tune_get("rpat_nt_rows")       # the launcher picks NT = true here
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    R = dA.pack()
+    assert isinstance(R, ops.RowPatterns) and R.npat == 2 and R.max_len == 5
+    rng = np.random.default_rng(4097)
+    x, b = rng.standard_normal(n), rng.standard_normal(n)
+    dx, db = dev(x), dev(b)
+    out = torch.empty(n, dtype=torch.float64, device=DEV)
+    for omega in (0.8, 1.0):
+        ops.csr_jacobi(dA, dx, db, omega, out)
+        assert np.array_equal(out.cpu().numpy(), K.jacobi(A, x, b, omega)), omega
+    part = torch.empty(ops.partials_count(n), dtype=torch.float64, device=DEV)
+    n2 = torch.zeros(1, dtype=torch.float64, device=DEV)
+    ops.csr_residual_norm2(dA, dx, db, out, part, n2)
+    wr, wn2 = K.residual(A, x, b)
+    assert np.array_equal(out.cpu().numpy(), wr)
+    assert abs(n2.item() - wn2) <= 1e-13 * wn2
+    y0 = rng.standard_normal(n)
+    y = dev(y0.copy())
+    ops.csr_spmv(dA, dx, y, 1.0, 1.0)
+    assert np.array_equal(y.cpu().numpy(), K.spmv(A, x, y0, 1.0, 1.0))
+    # the packed twin and the plain CSR kernel at the same size (what --no-patterns / --no-packed time)
+    dB = ops.DeviceCSR.from_scipy(A, DEV)
+    assert isinstance(dB.pack(patterns=False), ops.PackedCSR)
+    want = K.jacobi(A, x, b, 0.8)
+    ops.csr_jacobi(dB, dx, db, 0.8, out)
+    assert np.array_equal(out.cpu().numpy(), want)
+    try:
+        ops.set_packed_enabled(False)
+        ops.csr_jacobi(dB, dx, db, 0.8, out)
+        assert np.array_equal(out.cpu().numpy(), want)
+    finally:
+        ops.set_packed_enabled(True)
 
 
 def test_row_patterns_are_refused_when_rows_do_not_repeat():

@@ -35,8 +35,13 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB
 
 # HBM bytes per launch of the fine-level Jacobi sweep from rocprofv3 PMC passes
 # (2 x FETCH_SIZE [gfx950 counts wide reads at half size] + WRITE_SIZE, KB -> B), keyed by
-# (--size, fine-level format); see profiles/ for the runs these come from.  None = not measured.
-PMC_TRAFFIC = {(4096, "csr"): 1485261824, (4096, "pcsr"): 672639665, (4096, "rpat"): 451701453}
+# (--size, fine-level format).  NOT measured in this run (counters need their own rocprofv3 pass):
+# each entry names the committed profile it was read from, and the JSON line repeats that.
+PMC_TRAFFIC = {
+    (4096, "csr"): (1485261824, "profiles/r01_csr_sweepmode_pmc_fetch_write.txt"),
+    (4096, "pcsr"): (672639665, "profiles/r01_packed_sweep_pmc_fetch_write.txt"),
+    (4096, "rpat"): (451701453, "profiles/r01_rpat_sweep_pmc_fetch_write.txt"),
+}
 
 
 def sweep_bytes(n, nnz):

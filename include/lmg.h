@@ -127,6 +127,26 @@ int lmg_rpat_verify(int64_t n, int64_t ncols, const int32_t *d_rowptr, const int
                     const double *d_vals, const uint8_t *d_pid, int32_t npat, const int32_t *d_pat_ptr,
                     const int32_t *d_pat_off, const double *d_pat_val, int32_t *d_mismatch, void *stream);
 
+/* ---- grid-stencil sweeps: row-pattern matrices whose patterns are 3x3 stencils ------------
+ * A row-pattern matrix (d_pid as above) qualifies when every entry of every pattern sits at
+ * column - row = c * line_stride + d with c, d in {-1, 0, 1} and every pattern lists its entries in
+ * ascending column order: the 5-point operator of configs #2 / #4, its 9-point Galerkin
+ * coarsenings, tridiagonal 1-D operators.  The pattern table is then stored by SLOT:
+ *   d_st_val[npat * 9]   value of slot (c+1)*3 + (d+1) of every pattern (unused slots: anything)
+ *   d_st_mask[npat]      bit s set = slot s present in the pattern
+ *   union_mask           OR of all d_st_mask (slots nobody uses are never loaded)
+ * (learnmultigrid_amd/ops.py StencilTwin.from_patterns derives line_stride and the table from a
+ * verified RowPatterns twin and refuses everything else; at most lmg_stencil_limits patterns.)
+ * A lane owns two consecutive rows, reads x with three 16-byte loads and shares the left / right
+ * neighbours inside the wave -- 7 vector-memory instructions per 128 rows instead of 16-24 -- and
+ * accumulates every row's entries in ascending column order: same modes, argument meaning and bits
+ * as lmg_rpat_sweep.  d_x, d_b, d_out must be 16-byte aligned; square matrices only (x has n entries). */
+int lmg_stencil_limits(int32_t *max_patterns);
+int lmg_stencil_sweep(int mode, int64_t n, int32_t line_stride, const uint8_t *d_pid, int32_t npat,
+                      const double *d_st_val, const int32_t *d_st_mask, uint32_t union_mask, const double *d_x,
+                      const double *d_b, double *d_out, double alpha, double beta, double *d_partials,
+                      double *d_norm2, void *stream);
+
 /* ---- sliced-ELL ("SELL-64") sweeps: matrices with long rows ---------------------------
  * Third lossless twin.  Slice s = rows 64 s .. 64 s + 63, padded to its longest row
  * d_slice_len[s]; entry j of row r lives at d_slice_base[s] + 64 j + (r mod 64) of d_col

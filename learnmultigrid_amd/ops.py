@@ -37,7 +37,7 @@ def _vec_ok(*ts):
 class DeviceCSR:
     """CSR matrix resident in HBM: int32 rowptr[n+1], int32 colidx[nnz], fp64 vals[nnz]."""
 
-    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz", "packed", "patterns", "sell")
+    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz", "packed", "patterns", "sell", "stencil")
 
     def __init__(self, rowptr, colidx, vals, shape):
         if rowptr.dtype != I32 or colidx.dtype != I32 or vals.dtype != F64:
@@ -50,6 +50,7 @@ class DeviceCSR:
         self.packed = None           # PackedCSR twin used by the sweeps once pack() was called
         self.patterns = None         # RowPatterns twin (matrices with repeating rows), preferred
         self.sell = None             # SellCSR twin (long rows with all-distinct values)
+        self.stencil = None          # StencilTwin view of `patterns` (3x3 grid stencils), preferred
 
     def pack(self, patterns=None):
         """Build (once) the lossless twin the sweep kernels prefer; keeps the CSR arrays.
@@ -61,6 +62,7 @@ class DeviceCSR:
             patterns = _PATTERNS_ENABLED
         if patterns and self.patterns is None and self.packed is None:
             self.patterns = RowPatterns.from_csr(self)
+            self.stencil = StencilTwin.from_patterns(self.patterns, self.shape) if _STENCIL_ENABLED else None
         if patterns and self.patterns is not None:
             return self.patterns
         if self.sell is not None:
@@ -83,11 +85,13 @@ class DeviceCSR:
         self.packed = None
         self.patterns = None
         self.sell = None
+        self.stencil = None
 
     def repack_values(self):
         """After the values changed in place: refresh the twins (cheaply if possible)."""
         if self.patterns is not None:
             self.patterns = RowPatterns.from_csr(self)
+            self.stencil = StencilTwin.from_patterns(self.patterns, self.shape) if _STENCIL_ENABLED else None
             if self.patterns is None:
                 self.pack()
         if self.sell is not None:
@@ -395,8 +399,96 @@ class RowPatterns:
         return int(self.bytes_)
 
 
+class StencilTwin:
+    """3x3-stencil view of a RowPatterns twin for lmg_stencil_sweep (see include/lmg.h): every entry
+    of every pattern at  column - row = c * W + d,  c, d in {-1, 0, 1},  for ONE line stride W, every
+    pattern in ascending column order.  Derived from the (already verified) pattern table on the host
+    -- a few hundred numbers --; the per-row pattern ids are shared with the RowPatterns twin.
+    from_patterns returns None for everything that does not fit (the RPAT kernel then runs)."""
+
+    __slots__ = ("n", "W", "npat", "pid", "st_val", "st_mask", "umask", "bytes_", "patterns")
+
+    @staticmethod
+    def _decompose(off, W):
+        """(c, d) of a linear offset for line stride W, or None."""
+        for c in (-1, 0, 1):
+            d = off - c * W
+            if -1 <= d <= 1:
+                return c, d
+        return None
+
+    @classmethod
+    def from_patterns(cls, R, shape):
+        if R is None or shape[0] != shape[1] or R.n < 2:
+            return None
+        mp = ctypes.c_int32(0)
+        check(_lib.lib().lmg_stencil_limits(ctypes.addressof(mp)), "lmg_stencil_limits")
+        if R.npat > int(mp.value):
+            return None
+        ptr = R.pat_ptr.cpu().numpy()
+        off = R.pat_off.cpu().numpy().astype(np.int64)[: R.nent]
+        val = R.pat_val.cpu().numpy()[: R.nent]
+        for p in range(R.npat):
+            o = off[ptr[p]:ptr[p + 1]]
+            if o.size > 9 or np.any(np.diff(o) <= 0):            # slot order must be storage order
+                return None
+        mx = int(np.abs(off).max()) if off.size else 0
+        if mx <= 1:
+            cands = [max(3, int(R.n) - 1)]                        # 1-D: only the centre line is used
+            if R.n - 1 < 3:
+                return None
+        else:
+            cands = [w for w in (mx, mx - 1, mx + 1) if 3 <= w < R.n]
+        for W in cands:
+            slots = [cls._decompose(int(o), W) for o in off]
+            if all(sl is not None for sl in slots):
+                break
+        else:
+            return None
+        st_val = np.zeros(R.npat * 9)
+        st_mask = np.zeros(R.npat, dtype=np.int32)
+        for p in range(R.npat):
+            for j in range(ptr[p], ptr[p + 1]):
+                c, d = slots[j]
+                sidx = (c + 1) * 3 + (d + 1)
+                if st_mask[p] & (1 << sidx):
+                    return None
+                st_mask[p] |= 1 << sidx
+                st_val[p * 9 + sidx] = val[j]
+        dev = R.pid.device
+        self = cls()
+        self.n, self.W, self.npat, self.pid, self.patterns = int(R.n), int(W), int(R.npat), R.pid, R
+        self.st_val = torch.from_numpy(st_val).to(dev)
+        self.st_mask = torch.from_numpy(st_mask).to(dev)
+        self.umask = int(np.bitwise_or.reduce(st_mask)) if R.npat else 0
+        self.bytes_ = R.n + 76 * R.npat
+        return self
+
+    def bytes(self):
+        return int(self.bytes_)
+
+
 _PACKED_ENABLED = True
 _PATTERNS_ENABLED = True
+_STENCIL_ENABLED = True
+
+
+def set_stencil_enabled(flag):
+    """Whether 3x3-stencil row-pattern matrices run lmg_stencil_sweep (default) or lmg_rpat_sweep."""
+    global _STENCIL_ENABLED
+    _STENCIL_ENABLED = bool(flag)
+
+
+def _stencil(mode, S, x, b, out, alpha, beta, partials, norm2):
+    return _lib.lib().lmg_stencil_sweep(mode, S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask,
+                                        _p(x), _p(b), _p(out), float(alpha), float(beta), _p(partials), _p(norm2),
+                                        _s())
+
+
+def _use_stencil(A, *vecs):
+    if not (_PACKED_ENABLED and _STENCIL_ENABLED and A.stencil is not None):
+        return False
+    return all(v is None or v.data_ptr() % 16 == 0 for v in vecs)
 _SELL_ENABLED = True
 SELL_MIN_AVG = 12.0          # average row length from which the sliced-ELL twin replaces the packed CSR
 
@@ -456,6 +548,9 @@ def tune_get(key):
 def csr_residual_norm2(A, x, b, r, partials, norm2):
     """r = b - A x (r may be None), norm2[0] = sum r_i^2 (partials/norm2 may both be None)."""
     _vec_ok(x, b, r, partials, norm2)
+    if _use_stencil(A, x, b, r):
+        check(_stencil(0, A.stencil, x, b, r, 0.0, 0.0, partials, norm2), "lmg_stencil_sweep(residual)")
+        return
     if _PACKED_ENABLED and A.patterns is not None:
         check(_rpat(0, A.patterns, x, b, r, 0.0, 0.0, partials, norm2), "lmg_rpat_sweep(residual)")
         return
@@ -474,6 +569,9 @@ def csr_residual_norm2(A, x, b, r, partials, norm2):
 
 def csr_jacobi(A, x_in, b, omega, x_out):
     _vec_ok(x_in, b, x_out)
+    if _use_stencil(A, x_in, b, x_out):
+        check(_stencil(1, A.stencil, x_in, b, x_out, omega, 0.0, None, None), "lmg_stencil_sweep(jacobi)")
+        return
     if _PACKED_ENABLED and A.patterns is not None:
         check(_rpat(1, A.patterns, x_in, b, x_out, omega, 0.0, None, None), "lmg_rpat_sweep(jacobi)")
         return
@@ -493,6 +591,9 @@ def csr_spmv(A, x, y, alpha=1.0, beta=0.0):
     _vec_ok(x, y)
     if x.numel() != A.shape[1] or y.numel() != A.shape[0]:
         raise ValueError("spmv shape mismatch: A %s, x %d, y %d" % (A.shape, x.numel(), y.numel()))
+    if _use_stencil(A, x, y):
+        check(_stencil(2, A.stencil, x, None, y, alpha, beta, None, None), "lmg_stencil_sweep(spmv)")
+        return
     if _PACKED_ENABLED and A.patterns is not None:
         check(_rpat(2, A.patterns, x, None, y, alpha, beta, None, None), "lmg_rpat_sweep(spmv)")
         return

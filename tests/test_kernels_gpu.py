@@ -754,11 +754,22 @@ def rpat_case(name):
 
 @pytest.mark.parametrize("name", ["poisson2d_129", "poisson1d", "galerkin_9pt", "galerkin_l2_rounded",
                                   "with_empty_and_diagless_rows", "duplicate_diagonal"])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, "stencil"])
 @pytest.mark.parametrize("nt", [False, True], ids=["cached", "nontemporal"])
 def test_row_pattern_sweeps_bit_exact(name, variant, nt):
     """nt=True forces the NT = true instantiations (nontemporal id / b loads and out stores) that the
-    launcher otherwise only picks from 8 M rows on -- the ones the headline bench times."""
+    launchers otherwise only pick from 8 M rows on -- the ones the headline bench times.
+    variant "stencil": the grid-stencil kernel (stencil.hip) on the same twin, for the matrices whose
+    patterns are 3x3 stencils; variants 0..4: the tile geometries of the row-pattern kernel (rpat.hip)."""
+    stencil = variant == "stencil"
+    eligible = name in ("poisson2d_129", "poisson1d", "galerkin_9pt", "with_empty_and_diagless_rows")
+    if stencil and not eligible:
+        # 25-entry rows / unsorted duplicate entries are no 3x3 stencils: the builder must refuse them
+        A = rpat_case(name)
+        dA = (ops.DeviceCSR(dev(A.indptr.astype(np.int32)), dev(A.indices.astype(np.int32)), dev(A.data), A.shape)
+              if name == "duplicate_diagonal" else ops.DeviceCSR.from_scipy(A, DEV))
+        assert isinstance(dA.pack(), ops.RowPatterns) and dA.stencil is None
+        return
     A = rpat_case(name)
     n = A.shape[0]
     keys, ids = _numpy_row_patterns(A)
@@ -768,6 +779,15 @@ def test_row_pattern_sweeps_bit_exact(name, variant, nt):
         dA = ops.DeviceCSR.from_scipy(A, DEV)
     R = dA.pack()
     assert isinstance(R, ops.RowPatterns) and dA.packed is None
+    assert (dA.stencil is not None) == eligible
+    if eligible:
+        S = dA.stencil
+        expect_W = {"poisson2d_129": 129, "galerkin_9pt": None, "with_empty_and_diagless_rows": 41}.get(name)
+        if expect_W:
+            assert S.W == expect_W
+        assert S.pid is R.pid and S.npat == R.npat
+        assert bool(S.umask & 0x145) == (name == "galerkin_9pt")          # corner slots: 9-point only
+        assert bool(S.umask & 0x1C7) == (name != "poisson1d")
     assert R.npat == len(keys) and R.nent == sum(len(k[0]) for k in keys) and R.max_len == max(len(k[0]) for k in keys)
     # same partition of the rows into patterns, and every pattern reproduces its rows
     pid = R.pid.cpu().numpy()
@@ -803,12 +823,15 @@ def test_row_pattern_sweeps_bit_exact(name, variant, nt):
             return o
     Ac = A
     nt_default = ops.tune_get("rpat_nt_rows")
-    assert nt_default == 1 << 23
+    assert nt_default == 1 << 23 and ops.tune_get("stencil_nt_rows") == 1 << 23
     try:
-        ops.tune_set("rpat_variant", variant)
+        ops.set_stencil_enabled(stencil)
+        if not stencil:
+            ops.tune_set("rpat_variant", variant)
         if nt:
             ops.tune_set("rpat_nt_rows", 1)
-            assert ops.tune_get("rpat_nt_rows") == 1
+            ops.tune_set("stencil_nt_rows", 1)
+            assert ops.tune_get("rpat_nt_rows") == 1 and ops.tune_get("stencil_nt_rows") == 1
         for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (-0.5, 2.0)):
             y = dev(y0.copy())
             ops.csr_spmv(dA, dev(x), y, alpha, beta)
@@ -834,36 +857,48 @@ def test_row_pattern_sweeps_bit_exact(name, variant, nt):
         assert torch.equal(out, out2)
     finally:
         ops.set_packed_enabled(True)
+        ops.set_stencil_enabled(True)
         ops.tune_set("rpat_variant", 0)
         ops.tune_set("rpat_nt_rows", nt_default)
+        ops.tune_set("stencil_nt_rows", nt_default)
 
 
 def test_row_pattern_sweeps_full_size_4097_bit_exact_vs_oracle():
-    """The instantiations the headline bench times -- rpat_sweep_kernel<JACOBI|RESIDUAL, 5, 2, NT = true>
-    on the 16.8 M-row fine level of cfg#4 -- against oracle/lmg_oracle.c, bitwise, at full size."""
+    """The instantiations the headline bench times -- stencil_sweep_kernel<JACOBI|RESIDUAL, NT = true> on
+    the 16.8 M-row fine level of cfg#4 (and rpat_sweep_kernel<.., 5, 2, NT = true>, its fallback) --
+    against oracle/lmg_oracle.c, bitwise, at full size."""
     A = K.as_csr(P.poisson_2d_structured(4096)[0])
     n = A.shape[0]
-    assert n == 4097 * 4097 and n >= ops.tune_get("rpat_nt_rows")       # the launcher picks NT = true here
+    assert n == 4097 * 4097 and n >= ops.tune_get("rpat_nt_rows") and n >= ops.tune_get("stencil_nt_rows")
     dA = ops.DeviceCSR.from_scipy(A, DEV)
     R = dA.pack()
     assert isinstance(R, ops.RowPatterns) and R.npat == 2 and R.max_len == 5
+    assert dA.stencil is not None and dA.stencil.W == 4097 and dA.stencil.umask == 0b010111010
     rng = np.random.default_rng(4097)
     x, b = rng.standard_normal(n), rng.standard_normal(n)
     dx, db = dev(x), dev(b)
     out = torch.empty(n, dtype=torch.float64, device=DEV)
-    for omega in (0.8, 1.0):
-        ops.csr_jacobi(dA, dx, db, omega, out)
-        assert np.array_equal(out.cpu().numpy(), K.jacobi(A, x, b, omega)), omega
+    want_j = {omega: K.jacobi(A, x, b, omega) for omega in (0.8, 1.0)}
+    wr, wn2 = K.residual(A, x, b)
+    y0 = rng.standard_normal(n)
+    want_y = K.spmv(A, x, y0, 1.0, 1.0)
     part = torch.empty(ops.partials_count(n), dtype=torch.float64, device=DEV)
     n2 = torch.zeros(1, dtype=torch.float64, device=DEV)
-    ops.csr_residual_norm2(dA, dx, db, out, part, n2)
-    wr, wn2 = K.residual(A, x, b)
-    assert np.array_equal(out.cpu().numpy(), wr)
-    assert abs(n2.item() - wn2) <= 1e-13 * wn2
-    y0 = rng.standard_normal(n)
-    y = dev(y0.copy())
-    ops.csr_spmv(dA, dx, y, 1.0, 1.0)
-    assert np.array_equal(y.cpu().numpy(), K.spmv(A, x, y0, 1.0, 1.0))
+    try:
+        for stencil in (True, False):
+            ops.set_stencil_enabled(stencil)
+            for omega in (0.8, 1.0):
+                out.zero_()
+                ops.csr_jacobi(dA, dx, db, omega, out)
+                assert np.array_equal(out.cpu().numpy(), want_j[omega]), (stencil, omega)
+            ops.csr_residual_norm2(dA, dx, db, out, part, n2)
+            assert np.array_equal(out.cpu().numpy(), wr), stencil
+            assert abs(n2.item() - wn2) <= 1e-13 * wn2
+            y = dev(y0.copy())
+            ops.csr_spmv(dA, dx, y, 1.0, 1.0)
+            assert np.array_equal(y.cpu().numpy(), want_y), stencil
+    finally:
+        ops.set_stencil_enabled(True)
     # the packed twin and the plain CSR kernel at the same size (what --no-patterns / --no-packed time)
     dB = ops.DeviceCSR.from_scipy(A, DEV)
     assert isinstance(dB.pack(patterns=False), ops.PackedCSR)

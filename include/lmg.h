@@ -127,6 +127,27 @@ int lmg_rpat_verify(int64_t n, int64_t ncols, const int32_t *d_rowptr, const int
                     const double *d_vals, const uint8_t *d_pid, int32_t npat, const int32_t *d_pat_ptr,
                     const int32_t *d_pat_off, const double *d_pat_val, int32_t *d_mismatch, void *stream);
 
+/* Row patterns of RECTANGULAR grid operators (transfers between nested grids), SpMV only.  A pattern
+ * then stores  column - base(row)  with, for y = row / row_len and x = row % row_len,
+ *     base(row) = (y >> ysh) * col_stride + ((x >> xsh) << xshl),
+ * h_grid_map = HOST pointer to {row_len, col_stride, ysh, xsh, xshl} (NULL or row_len 0: base(row) =
+ * row, i.e. the functions above).  Restriction R = P^T of a tensor-product interpolator between a
+ * Wf x Wf and a Wc x Wc grid: {Wc, 2 Wf, 0, 0, 1}; its prolongation P: {Wf, Wc, 1, 1, 0}; 1-D
+ * transfers: row_len > number of rows.  The format stays a verified lossless re-encoding: the builder
+ * (ops.RowPatterns.from_csr(A, grid_map)) tries a map, and lmg_rpat_verify_grid checks every entry.
+ * u += P e and r_c = R r then move the vectors and one byte per row instead of 10-12 bytes per entry.
+ * Replaces the same SciPy calls as lmg_csr_spmv (Multigrid.py:93, :115). */
+int lmg_rpat_sweep_grid(int mode, int64_t n, const int32_t *h_grid_map, const uint8_t *d_pid, int32_t npat,
+                        int32_t nent, int32_t max_len, const int32_t *d_pat_ptr, const int32_t *d_pat_off,
+                        const double *d_pat_val, const double *d_x, const double *d_b, double *d_out,
+                        double alpha, double beta, double *d_partials, double *d_norm2, void *stream);
+int lmg_rpat_row_hash_grid(int64_t n, const int32_t *h_grid_map, const int32_t *d_rowptr,
+                           const int32_t *d_colidx, const double *d_vals, uint64_t *d_hash, void *stream);
+int lmg_rpat_verify_grid(int64_t n, int64_t ncols, const int32_t *h_grid_map, const int32_t *d_rowptr,
+                         const int32_t *d_colidx, const double *d_vals, const uint8_t *d_pid, int32_t npat,
+                         const int32_t *d_pat_ptr, const int32_t *d_pat_off, const double *d_pat_val,
+                         int32_t *d_mismatch, void *stream);
+
 /* ---- grid-stencil sweeps: row-pattern matrices whose patterns are 3x3 stencils ------------
  * A row-pattern matrix (d_pid as above) qualifies when every entry of every pattern sits at
  * column - row = c * line_stride + d with c, d in {-1, 0, 1} and every pattern lists its entries in

@@ -41,6 +41,9 @@ SIGNATURES = {
     "lmg_rpat_row_hash": (_c.c_int, [_i64, _p, _p, _p, _p, _p]),
     "lmg_rpat_claim": (_c.c_int, [_i64, _p, _p, _p]),
     "lmg_rpat_verify": (_c.c_int, [_i64, _i64, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
+    "lmg_rpat_sweep_grid": (_c.c_int, [_c.c_int, _i64, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _f64, _f64, _p, _p, _p]),
+    "lmg_rpat_row_hash_grid": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p]),
+    "lmg_rpat_verify_grid": (_c.c_int, [_i64, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p]),
     "lmg_stencil_limits": (_c.c_int, [_p]),
     "lmg_stencil_sweep": (_c.c_int, [_c.c_int, _i64, _i32, _p, _i32, _p, _p, _c.c_uint32, _p, _p, _p, _f64, _f64, _p, _p, _p]),
     "lmg_sell_sweep": (_c.c_int, [_c.c_int, _i64, _p, _p, _p, _p, _p, _c.c_int, _p, _i32, _p, _p, _p, _f64, _f64, _p, _p, _p]),

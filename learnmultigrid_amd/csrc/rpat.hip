@@ -27,7 +27,34 @@ constexpr int kBlock = 256;
 constexpr int kMaxPat = 256;      // pattern ids are uint8; id 255 is never used by the builder
 constexpr int kMaxEnt = 1024;     // total entries of all patterns (LDS: 12 KB)
 
+// Column base of a row for RECTANGULAR grid operators (transfers between nested grids): with
+// y = row / row_len, x = row % row_len,
+//     base(row) = (y >> ysh) * col_stride + ((x >> xsh) << xshl),
+// and a pattern stores  column - base(row).  Restriction R = P^T of the tensor-product interpolator
+// (coarse row (Y, X) reads fine columns (2Y+dy) * Wf + 2X + dx): row_len = Wc, col_stride = 2 Wf,
+// xshl = 1.  Prolongation P (fine row (y, x) reads coarse columns around (y >> 1, x >> 1)): row_len =
+// Wf, col_stride = Wc, ysh = xsh = 1.  1-D transfers: row_len > number of rows (y = 0).
+// row_len == 0 means base(row) = row (square operators).
+struct GridMap {
+    int row_len;
+    int col_stride;
+    int ysh, xsh, xshl;
+    unsigned magic;             // floor(2^32 / row_len)
+};
+
+__device__ __forceinline__ int lmg_grid_base(const GridMap &m, int row)
+{
+    unsigned y = __umulhi((unsigned)row, m.magic);                  // row / row_len or one less (row < 2^31)
+    unsigned x = (unsigned)row - y * (unsigned)m.row_len;
+    if (x >= (unsigned)m.row_len) {
+        x -= (unsigned)m.row_len;
+        ++y;
+    }
+    return (int)((y >> m.ysh) * (unsigned)m.col_stride + ((x >> m.xsh) << m.xshl));
+}
+
 struct RArgs {
+    GridMap map;
     int n;
     int tiles;
     int tiles_per_xcd;
@@ -50,7 +77,7 @@ struct RArgs {
 #ifndef LMG_RPAT_NT_MODE
 #define LMG_RPAT_NT_MODE 3          // bit 0: nontemporal loads of ids / b, bit 1: nontemporal stores of out
 #endif
-template <int MODE, int JU, int kRpt, bool NT>
+template <int MODE, int JU, int kRpt, bool NT, bool MAP = false>
 __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
 {
     constexpr bool NTL = NT && (LMG_RPAT_NT_MODE & 1), NTS = NT && (LMG_RPAT_NT_MODE & 2);
@@ -105,12 +132,13 @@ __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
     auto process = [&](int tile, const int (&pat)[kRpt], const double (&bv)[kRpt]) {
         const int r0 = tile * kTileRows;
         double local = 0.0;
-        int row[kRpt], ps[kRpt], len[kRpt];
+        int row[kRpt], cb[kRpt], ps[kRpt], len[kRpt];
         double acc[kRpt], xi[kRpt];
         int maxlen = 0;
 #pragma unroll
         for (int k = 0; k < kRpt; ++k) {
             row[k] = r0 + k * kBlock + t;
+            cb[k] = MAP ? lmg_grid_base(a.map, row[k] < a.n ? row[k] : 0) : row[k];
             ps[k] = s_ptr[pat[k]];
             len[k] = row[k] < a.n ? s_ptr[pat[k] + 1] - ps[k] : 0;
             maxlen = max(maxlen, len[k]);
@@ -135,7 +163,7 @@ __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
 #pragma unroll
                 for (int k = 0; k < kRpt; ++k) {
                     const bool act = j0 + jj < len[k];
-                    xv[jj][k] = a.x[act ? row[k] + off[jj][k] : 0];
+                    xv[jj][k] = a.x[act ? cb[k] + off[jj][k] : 0];
                 }
             }
 #pragma unroll
@@ -222,19 +250,19 @@ __global__ void __launch_bounds__(1024) rpat_reduce_partials_kernel(const double
 
 int g_rpat_variant = 0;      // 0 = pick from the longest pattern; 1..4 = forced (tuning)
 
-template <int MODE, int JU, int kRpt, bool NT>
+template <int MODE, int JU, int kRpt, bool NT, bool MAP = false>
 int launch_nt(RArgs a, hipStream_t st)
 {
     a.tiles = (a.n + kBlock * kRpt - 1) / (kBlock * kRpt);
     a.tiles_per_xcd = (a.tiles + 7) / 8;
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rpat_sweep_kernel<MODE, JU, kRpt, NT>, kBlock, 0) !=
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rpat_sweep_kernel<MODE, JU, kRpt, NT, MAP>, kBlock, 0) !=
             hipSuccess || per_cu < 1)
         per_cu = 4;
     if (per_cu > 8) per_cu = 8;
     int64_t grid = 256 * (int64_t)per_cu;
     if (grid > (int64_t)a.tiles_per_xcd * 8) grid = (int64_t)a.tiles_per_xcd * 8;
-    hipLaunchKernelGGL((rpat_sweep_kernel<MODE, JU, kRpt, NT>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((rpat_sweep_kernel<MODE, JU, kRpt, NT, MAP>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
     LMG_CHECK_LAUNCH();
     return a.tiles;
 }
@@ -244,6 +272,9 @@ int g_rpat_nt_rows = 1 << 23;      // rows from which the id / b / out streams b
 template <int MODE, int JU, int kRpt>
 int launch_one(RArgs a, hipStream_t st)
 {
+    if (MODE == MODE_SPMV && a.map.row_len > 0)       // rectangular grid operators (transfers): SpMV only
+        return a.n >= g_rpat_nt_rows ? launch_nt<MODE_SPMV, JU, kRpt, true, true>(a, st)
+                                     : launch_nt<MODE_SPMV, JU, kRpt, false, true>(a, st);
     return a.n >= g_rpat_nt_rows ? launch_nt<MODE, JU, kRpt, true>(a, st) : launch_nt<MODE, JU, kRpt, false>(a, st);
 }
 
@@ -252,7 +283,9 @@ int launch(RArgs a, int maxlen, hipStream_t st)
 {
     int v = g_rpat_variant;
     // measured on MI355X (tools/time_rpat.py): all geometries are within 10 % of each other
-    if (v == 0) v = maxlen <= 5 ? 2 : 4;
+    // (prolongations of nested grids -- rows of 1, 2 or 4 entries, read-modify-write of the fine vector --
+    // want more rows in flight per lane: 4097^2 <- 2049^2 0.083 ms with geometry 3 vs 0.090-0.100)
+    if (v == 0) v = (a.map.row_len > 0 && maxlen <= 4) ? 3 : (maxlen <= 5 ? 2 : 4);
     switch (v) {
     case 1: return launch_one<MODE, 5, 1>(a, st);
     case 2: return launch_one<MODE, 5, 2>(a, st);
@@ -272,7 +305,7 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long k)
 }
 
 // 64-bit hash of (length; column - row, value bits ...) of every row; never the all-ones value
-__global__ void __launch_bounds__(256) row_pattern_hash_kernel(int64_t n, const int *__restrict__ rowptr,
+__global__ void __launch_bounds__(256) row_pattern_hash_kernel(int64_t n, GridMap map, const int *__restrict__ rowptr,
                                                                const int *__restrict__ colidx,
                                                                const unsigned long long *__restrict__ vbits,
                                                                unsigned long long *__restrict__ hash)
@@ -280,9 +313,10 @@ __global__ void __launch_bounds__(256) row_pattern_hash_kernel(int64_t n, const 
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int s = rowptr[i], e = rowptr[i + 1];
+    const int base = map.row_len > 0 ? lmg_grid_base(map, (int)i) : (int)i;
     unsigned long long h = mix64(0x9E3779B97F4A7C15ull + (unsigned long long)(e - s));
     for (int j = s; j < e; ++j) {
-        h = mix64(h ^ (unsigned long long)(unsigned)(colidx[j] - (int)i));
+        h = mix64(h ^ (unsigned long long)(unsigned)(colidx[j] - base));
         h = mix64(h ^ vbits[j]);
     }
     if (h == ~0ull) h = 0;
@@ -301,7 +335,8 @@ __global__ void __launch_bounds__(256) pattern_claim_kernel(int64_t n, const uns
 }
 
 // every row against its pattern, entry by entry (hash collisions must not pass)
-__global__ void __launch_bounds__(256) pattern_verify_kernel(int64_t n, int64_t ncols, const int *__restrict__ rowptr,
+__global__ void __launch_bounds__(256) pattern_verify_kernel(int64_t n, int64_t ncols, GridMap map,
+                                                             const int *__restrict__ rowptr,
                                                              const int *__restrict__ colidx,
                                                              const unsigned long long *__restrict__ vbits,
                                                              const unsigned char *__restrict__ pid, int npat,
@@ -316,10 +351,11 @@ __global__ void __launch_bounds__(256) pattern_verify_kernel(int64_t n, int64_t 
     bool ok = p < npat;
     if (ok) {
         const int s = rowptr[i], e = rowptr[i + 1], ps = pat_ptr[p];
+        const int base = map.row_len > 0 ? lmg_grid_base(map, (int)i) : (int)i;
         ok = (e - s) == pat_ptr[p + 1] - ps;
         for (int j = 0; ok && j < e - s; ++j) {
             const int c = colidx[s + j];
-            ok = (c - (int)i == pat_off[ps + j]) && (vbits[s + j] == pat_vbits[ps + j]) && c >= 0 && c < ncols;
+            ok = (c - base == pat_off[ps + j]) && (vbits[s + j] == pat_vbits[ps + j]) && c >= 0 && c < ncols;
         }
     }
     if (!ok) *mismatch = 1;
@@ -354,11 +390,41 @@ int lmg_rpat_limits(int32_t *max_patterns, int32_t *max_entries)
     return LMG_OK;
 }
 
+// h_grid_map: NULL / row_len 0 = square operator, else {row_len, col_stride, ysh, xsh, xshl}
+static int make_grid_map(const int32_t *h, GridMap *m)
+{
+    m->row_len = 0;
+    m->col_stride = 0;
+    m->ysh = m->xsh = m->xshl = 0;
+    m->magic = 0;
+    if (!h || h[0] == 0) return LMG_OK;
+    if (h[0] < 1 || h[1] < 0 || h[2] < 0 || h[2] > 1 || h[3] < 0 || h[3] > 1 || h[4] < 0 || h[4] > 1) return LMG_ERR_ARG;
+    m->row_len = h[0];
+    m->col_stride = h[1];
+    m->ysh = h[2];
+    m->xsh = h[3];
+    m->xshl = h[4];
+    m->magic = h[0] == 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned long long)h[0]);
+    return LMG_OK;
+}
+
 int lmg_rpat_sweep(int mode, int64_t n, const uint8_t *pid, int32_t npat, int32_t nent, int32_t max_len,
                    const int32_t *pat_ptr, const int32_t *pat_off, const double *pat_val, const double *x,
                    const double *b, double *out, double alpha, double beta, double *partials, double *norm2,
                    void *stream)
 {
+    return lmg_rpat_sweep_grid(mode, n, nullptr, pid, npat, nent, max_len, pat_ptr, pat_off, pat_val, x, b, out,
+                               alpha, beta, partials, norm2, stream);
+}
+
+int lmg_rpat_sweep_grid(int mode, int64_t n, const int32_t *h_grid_map, const uint8_t *pid, int32_t npat,
+                        int32_t nent, int32_t max_len, const int32_t *pat_ptr, const int32_t *pat_off,
+                        const double *pat_val, const double *x, const double *b, double *out, double alpha,
+                        double beta, double *partials, double *norm2, void *stream)
+{
+    GridMap gm;
+    if (make_grid_map(h_grid_map, &gm) != LMG_OK) return LMG_ERR_ARG;
+    if (gm.row_len > 0 && mode != MODE_SPMV) return LMG_ERR_ARG;         // rectangular operators: SpMV only
     if (n < 0 || n >= INT32_MAX || npat < 1 || npat >= kMaxPat || nent < 0 || nent > kMaxEnt) return LMG_ERR_ARG;
     if (n == 0) return LMG_OK;
     if (!pid || !pat_ptr || !x || (nent > 0 && (!pat_off || !pat_val))) return LMG_ERR_ARG;
@@ -372,6 +438,7 @@ int lmg_rpat_sweep(int mode, int64_t n, const uint8_t *pid, int32_t npat, int32_
         return LMG_ERR_ARG;
     }
     RArgs a;
+    a.map = gm;
     a.n = (int)n;
     a.tiles = a.tiles_per_xcd = 0;
     a.npat = npat;
@@ -402,11 +469,18 @@ int lmg_rpat_sweep(int mode, int64_t n, const uint8_t *pid, int32_t npat, int32_
 int lmg_rpat_row_hash(int64_t n, const int32_t *rowptr, const int32_t *colidx, const double *vals, uint64_t *hash,
                       void *stream)
 {
-    if (n < 0) return LMG_ERR_ARG;
+    return lmg_rpat_row_hash_grid(n, nullptr, rowptr, colidx, vals, hash, stream);
+}
+
+int lmg_rpat_row_hash_grid(int64_t n, const int32_t *h_grid_map, const int32_t *rowptr, const int32_t *colidx,
+                           const double *vals, uint64_t *hash, void *stream)
+{
+    GridMap gm;
+    if (n < 0 || n >= INT32_MAX || make_grid_map(h_grid_map, &gm) != LMG_OK) return LMG_ERR_ARG;
     if (n == 0) return LMG_OK;
     if (!rowptr || !hash) return LMG_ERR_ARG;
     row_pattern_hash_kernel<<<(unsigned)((n + 255) / 256), 256, 0, lmg_stream(stream)>>>(
-        n, rowptr, colidx, reinterpret_cast<const unsigned long long *>(vals),
+        n, gm, rowptr, colidx, reinterpret_cast<const unsigned long long *>(vals),
         reinterpret_cast<unsigned long long *>(hash));
     LMG_CHECK_LAUNCH();
     return LMG_OK;
@@ -426,11 +500,21 @@ int lmg_rpat_verify(int64_t n, int64_t ncols, const int32_t *rowptr, const int32
                     const uint8_t *pid, int32_t npat, const int32_t *pat_ptr, const int32_t *pat_off,
                     const double *pat_val, int32_t *mismatch, void *stream)
 {
-    if (n < 0 || npat < 1) return LMG_ERR_ARG;
+    return lmg_rpat_verify_grid(n, ncols, nullptr, rowptr, colidx, vals, pid, npat, pat_ptr, pat_off, pat_val,
+                                mismatch, stream);
+}
+
+int lmg_rpat_verify_grid(int64_t n, int64_t ncols, const int32_t *h_grid_map, const int32_t *rowptr,
+                         const int32_t *colidx, const double *vals, const uint8_t *pid, int32_t npat,
+                         const int32_t *pat_ptr, const int32_t *pat_off, const double *pat_val, int32_t *mismatch,
+                         void *stream)
+{
+    GridMap gm;
+    if (n < 0 || n >= INT32_MAX || npat < 1 || make_grid_map(h_grid_map, &gm) != LMG_OK) return LMG_ERR_ARG;
     if (n == 0) return LMG_OK;
     if (!rowptr || !pid || !pat_ptr || !mismatch) return LMG_ERR_ARG;
     pattern_verify_kernel<<<(unsigned)((n + 255) / 256), 256, 0, lmg_stream(stream)>>>(
-        n, ncols, rowptr, colidx, reinterpret_cast<const unsigned long long *>(vals), pid, npat, pat_ptr, pat_off,
+        n, ncols, gm, rowptr, colidx, reinterpret_cast<const unsigned long long *>(vals), pid, npat, pat_ptr, pat_off,
         reinterpret_cast<const unsigned long long *>(pat_val), mismatch);
     LMG_CHECK_LAUNCH();
     return LMG_OK;

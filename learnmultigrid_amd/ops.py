@@ -6,6 +6,7 @@ arithmetic step is a hand-written gfx950 kernel reached through ctypes.  The sam
 Python callables back the `torch.ops.lmg.*` ops and the solver's internal calls.
 """
 import ctypes
+import math
 
 import numpy as np
 import torch
@@ -60,8 +61,15 @@ class DeviceCSR:
             return None
         if patterns is None:
             patterns = _PATTERNS_ENABLED
-        if patterns and self.patterns is None and self.packed is None:
-            self.patterns = RowPatterns.from_csr(self)
+        if patterns and self.patterns is None and self.packed is None and self.sell is None:
+            if self.shape[0] == self.shape[1]:
+                self.patterns = RowPatterns.from_csr(self)
+            else:
+                # rectangular grid operators (transfers): row patterns relative to a column-base map
+                for gm in (RowPatterns.grid_map_candidates(self.shape) if _GRID_MAPS_ENABLED else []):
+                    self.patterns = RowPatterns.from_csr(self, gm)
+                    if self.patterns is not None:
+                        break
             self.stencil = StencilTwin.from_patterns(self.patterns, self.shape) if _STENCIL_ENABLED else None
         if patterns and self.patterns is not None:
             return self.patterns
@@ -90,7 +98,7 @@ class DeviceCSR:
     def repack_values(self):
         """After the values changed in place: refresh the twins (cheaply if possible)."""
         if self.patterns is not None:
-            self.patterns = RowPatterns.from_csr(self)
+            self.patterns = RowPatterns.from_csr(self, self.patterns.grid_map)
             self.stencil = StencilTwin.from_patterns(self.patterns, self.shape) if _STENCIL_ENABLED else None
             if self.patterns is None:
                 self.pack()
@@ -343,20 +351,48 @@ class RowPatterns:
     rows and 1024 pattern entries qualify (assembled constant-coefficient grid operators and
     their Galerkin coarsenings); from_csr returns None for everything else."""
 
-    __slots__ = ("n", "nnz", "shape", "pid", "npat", "nent", "max_len", "pat_ptr", "pat_off", "pat_val", "bytes_")
+    __slots__ = ("n", "nnz", "shape", "pid", "npat", "nent", "max_len", "pat_ptr", "pat_off", "pat_val", "bytes_",
+                 "grid_map", "_gm")
+
+    @staticmethod
+    def grid_map_candidates(shape):
+        """Column-base maps worth trying for a RECTANGULAR operator (see lmg_rpat_sweep_grid): the
+        tensor-product transfer between two square grids when both dimensions are perfect squares, and
+        the 1-D transfer.  Nothing is assumed: a map is only used if every entry verifies."""
+        nr, nc = int(shape[0]), int(shape[1])
+        if nr == nc or nr < 2 or nc < 2:
+            return []
+        out = []
+        wr, wc = math.isqrt(nr), math.isqrt(nc)
+        if wr * wr == nr and wc * wc == nc and min(wr, wc) >= 2:
+            out.append((wr, wc, 1, 1, 0) if nr > nc else (wr, 2 * wc, 0, 0, 1))
+        out.append((nr + 1, 0, 0, 1, 0) if nr > nc else (nr + 1, 0, 0, 0, 1))
+        return out
+
+    @staticmethod
+    def grid_base(grid_map, rows):
+        """base(row) of lmg_rpat_sweep_grid for an int64 numpy array of rows."""
+        if grid_map is None:
+            return rows
+        rl, cs, ysh, xsh, xshl = grid_map
+        y, x = rows // rl, rows % rl
+        return (y >> ysh) * cs + ((x >> xsh) << xshl)
 
     @classmethod
-    def from_csr(cls, A):
+    def from_csr(cls, A, grid_map=None):
         n, nnz = A.shape[0], A.nnz
         if n == 0 or nnz == 0 or not A.vals.is_cuda:
             return None
         L = _lib.lib()
         dev = A.vals.device
+        gm = None if grid_map is None else (ctypes.c_int32 * 5)(*[int(v) for v in grid_map])
+        gmp = None if gm is None else ctypes.addressof(gm)
         mp, me = ctypes.c_int32(0), ctypes.c_int32(0)
         check(L.lmg_rpat_limits(ctypes.addressof(mp), ctypes.addressof(me)), "lmg_rpat_limits")
         max_pat, max_ent = int(mp.value), int(me.value)
         hashes = torch.empty(n, dtype=torch.int64, device=dev)
-        check(L.lmg_rpat_row_hash(n, _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(hashes), _s()), "lmg_rpat_row_hash")
+        check(L.lmg_rpat_row_hash_grid(n, gmp, _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(hashes), _s()),
+              "lmg_rpat_row_hash_grid")
         uniq = PackedCSR._distinct_values(hashes.view(F64), limit=max_pat)
         if uniq is None:
             return None
@@ -376,7 +412,6 @@ class RowPatterns:
             return None
         idx = np.concatenate([np.arange(s_, e_) for s_, e_ in zip(starts, ends)]) if nent else np.zeros(0, np.int64)
         d_idx = torch.from_numpy(idx).to(dev)
-        rows_of = torch.from_numpy(np.repeat(rep.cpu().numpy(), lens)).to(dev)
         self = cls()
         self.n, self.nnz, self.shape = n, nnz, A.shape
         self.pid = pid
@@ -385,14 +420,18 @@ class RowPatterns:
         ptr = np.zeros(npat + 1, dtype=np.int32)
         np.cumsum(lens, out=ptr[1:])
         self.pat_ptr = torch.from_numpy(ptr).to(dev)
-        self.pat_off = (A.colidx[d_idx].long() - rows_of).to(I32).contiguous() if nent else torch.zeros(1, dtype=I32, device=dev)
+        base_of = torch.from_numpy(cls.grid_base(grid_map, np.repeat(rep.cpu().numpy(), lens).astype(np.int64))).to(dev)
+        self.pat_off = (A.colidx[d_idx].long() - base_of).to(I32).contiguous() if nent else torch.zeros(1, dtype=I32, device=dev)
         self.pat_val = A.vals[d_idx].contiguous() if nent else torch.zeros(1, dtype=F64, device=dev)
         mismatch = torch.zeros(1, dtype=I32, device=dev)
-        check(L.lmg_rpat_verify(n, A.shape[1], _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(pid), npat, _p(self.pat_ptr),
-                                _p(self.pat_off), _p(self.pat_val), _p(mismatch), _s()), "lmg_rpat_verify")
+        check(L.lmg_rpat_verify_grid(n, A.shape[1], gmp, _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(pid), npat,
+                                     _p(self.pat_ptr), _p(self.pat_off), _p(self.pat_val), _p(mismatch), _s()),
+              "lmg_rpat_verify_grid")
         if int(mismatch):
             return None                                # a hash collision: not worth a second try
         self.bytes_ = n + 4 * (npat + 1) + 12 * nent
+        self.grid_map = None if grid_map is None else tuple(int(v) for v in grid_map)
+        self._gm = gm                                  # keeps the host array of the map alive
         return self
 
     def bytes(self):
@@ -471,6 +510,13 @@ class StencilTwin:
 _PACKED_ENABLED = True
 _PATTERNS_ENABLED = True
 _STENCIL_ENABLED = True
+_GRID_MAPS_ENABLED = True
+
+
+def set_grid_maps_enabled(flag):
+    """Whether pack() tries row patterns with a column-base map on rectangular operators (default)."""
+    global _GRID_MAPS_ENABLED
+    _GRID_MAPS_ENABLED = bool(flag)
 
 
 def set_stencil_enabled(flag):
@@ -519,9 +565,10 @@ def set_patterns_enabled(flag):
 
 
 def _rpat(mode, R, x, b, out, alpha, beta, partials, norm2):
-    return _lib.lib().lmg_rpat_sweep(mode, R.n, _p(R.pid), R.npat, R.nent, R.max_len, _p(R.pat_ptr), _p(R.pat_off),
-                                     _p(R.pat_val), _p(x), _p(b), _p(out), float(alpha), float(beta),
-                                     _p(partials), _p(norm2), _s())
+    gmp = None if R._gm is None else ctypes.addressof(R._gm)
+    return _lib.lib().lmg_rpat_sweep_grid(mode, R.n, gmp, _p(R.pid), R.npat, R.nent, R.max_len, _p(R.pat_ptr),
+                                          _p(R.pat_off), _p(R.pat_val), _p(x), _p(b), _p(out), float(alpha),
+                                          float(beta), _p(partials), _p(norm2), _s())
 
 
 def _pcsr(mode, P, x, b, out, alpha, beta, partials, norm2):

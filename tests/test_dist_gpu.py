@@ -82,9 +82,11 @@ def _gpu_worker(rank, world, port, out_dir, transfer="geometric"):
         assert D.host_staged and D.n_dist == 2
         if transfer == "geometric":
             # local operators run on their lossless twins: row patterns for the square grid operators
-            # (ghost rows are one more pattern), 16-bit packed columns for the transfers
+            # (ghost rows are one more pattern); the transfers on 16-bit packed columns, or -- local blocks of
+            # few grid lines -- on row patterns relative to the 1-D column map (verified entry by entry)
             assert all(d.A.patterns is not None for d in D.dl)
-            assert all(M.packed is not None and M.packed.colmode == 0 for d in D.dl for M in (d.R, d.P))
+            assert all((M.packed is not None and M.packed.colmode == 0) or M.patterns is not None
+                       for d in D.dl for M in (d.R, d.P))
         else:
             # 25-entry Galerkin rows and restrictions with all-distinct values: sliced ELL
             assert D.dl[1].A.sell is not None and D.dl[0].R.sell is not None

@@ -4,6 +4,8 @@ Bars: bit-exact for SpMV / residual / Jacobi / Gauss-Seidel / SpGEMM values and 
 integer outputs (same accumulation order, no FMA contraction on either side);
 1e-13 relative for the reductions whose summation tree differs (norms, dot, GEMV).
 """
+import math
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -913,8 +915,93 @@ def test_row_pattern_sweeps_full_size_4097_bit_exact_vs_oracle():
         ops.set_packed_enabled(True)
 
 
+@pytest.mark.parametrize("kind", ["tensor2d_odd", "tensor2d_even", "1d_odd", "1d_even", "l2_tensor2d"])
+@pytest.mark.parametrize("nt", [False, True], ids=["cached", "nontemporal"])
+def test_grid_transfer_row_patterns_bit_exact(kind, nt):
+    """Prolongation P and restriction R = P^T of nested grids as row patterns relative to a column-base
+    map (lmg_rpat_sweep_grid): u += P e (Multigrid.py:115) and r_c = R r (:93) bitwise against the
+    oracle's CSR loops, for the reference's 1-D interpolator (odd and even n: the even-n quirk of
+    Multigrid.py:139-142 is just more patterns), its tensor product, and the L2-type transfer."""
+    if kind.startswith("tensor2d"):
+        s = 65 if kind.endswith("odd") else 66
+        P1 = P.geometric_interpolator_1d(s)
+        Pm = sp.kron(P1, P1).tocsr()
+    elif kind.startswith("1d"):
+        Pm = P.geometric_interpolator_1d(3001 if kind.endswith("odd") else 3000).tocsr()
+    else:
+        l2 = P.pseudo_l2_interpolator_1d(65)
+        Pm = sp.kron(l2, l2).tocsr()
+    Pm = K.as_csr(Pm)
+    Rm = K.as_csr(sp.csr_matrix(Pm.T))
+    rng = np.random.default_rng(31)
+    nt_default = ops.tune_get("rpat_nt_rows")
+    try:
+        if nt:
+            ops.tune_set("rpat_nt_rows", 1)
+        for M in (Pm, Rm):
+            dM = ops.DeviceCSR.from_scipy(M, DEV)
+            R = dM.pack()
+            assert isinstance(R, ops.RowPatterns) and R.grid_map is not None and dM.packed is None, (kind, M.shape)
+            assert dM.stencil is None and R.bytes() < 0.2 * dM.bytes()
+            if kind.startswith("tensor2d") or kind == "l2_tensor2d":
+                assert R.grid_map[0] == math.isqrt(M.shape[0])            # the 2-D map, not the 1-D one
+            # the map, restated: every entry's column = base(row) + pattern offset
+            pid, ptr, off = R.pid.cpu().numpy(), R.pat_ptr.cpu().numpy(), R.pat_off.cpu().numpy()
+            for i in (0, 1, M.shape[0] // 3, M.shape[0] // 2, M.shape[0] - 2, M.shape[0] - 1):
+                s_, e_ = M.indptr[i], M.indptr[i + 1]
+                base = int(ops.RowPatterns.grid_base(R.grid_map, np.array([i], dtype=np.int64))[0])
+                assert np.array_equal(off[ptr[pid[i]]:ptr[pid[i] + 1]] + base, M.indices[s_:e_])
+            x, y0 = rng.standard_normal(M.shape[1]), rng.standard_normal(M.shape[0])
+            for variant in (0, 1, 2, 3, 4):
+                ops.tune_set("rpat_variant", variant)
+                for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (-0.5, 2.0)):
+                    y = dev(y0.copy())
+                    ops.csr_spmv(dM, dev(x), y, alpha, beta)
+                    assert np.array_equal(y.cpu().numpy(), K.spmv(M, x, y0, alpha, beta)), (kind, variant, alpha, beta)
+            # new values, same pattern (Galerkin rebuild path): the twin keeps its map
+            dM.vals.mul_(2.0)
+            dM.repack_values()
+            assert dM.patterns is not None and dM.patterns.grid_map == R.grid_map
+            y = dev(y0.copy())
+            ops.csr_spmv(dM, dev(x), y, 1.0, 0.0)
+            assert np.array_equal(y.cpu().numpy(), K.spmv(M * 2.0, x, y0, 1.0, 0.0))
+    finally:
+        ops.tune_set("rpat_variant", 0)
+        ops.tune_set("rpat_nt_rows", nt_default)
+
+
+def test_grid_maps_never_pass_unverified():
+    # learned-like transfers (all-distinct values) have no repeating rows under any map
+    base = sp.kron(P.pseudo_l2_interpolator_1d(65), P.pseudo_l2_interpolator_1d(65)).tocsr()
+    Q = K.as_csr(P.learned_like(base, 43))
+    for M in (Q, K.as_csr(sp.csr_matrix(Q.T))):
+        dM = ops.DeviceCSR.from_scipy(M, DEV)
+        tw = dM.pack()
+        assert dM.patterns is None and tw is not None
+        x = np.random.default_rng(3).standard_normal(M.shape[1])
+        y = torch.empty(M.shape[0], dtype=torch.float64, device=DEV)
+        ops.csr_spmv(dM, dev(x), y)
+        assert np.array_equal(y.cpu().numpy(), K.spmv(M, x, np.zeros(M.shape[0]), 1.0, 0.0))
+    # a tensor transfer with ONE entry perturbed still verifies (it is just one more pattern) ...
+    Pm = K.as_csr(sp.kron(P.geometric_interpolator_1d(33), P.geometric_interpolator_1d(33)).tocsr())
+    Pm.data[777] *= 1.5
+    dM = ops.DeviceCSR.from_scipy(Pm, DEV)
+    assert isinstance(dM.pack(), ops.RowPatterns)
+    x = np.random.default_rng(4).standard_normal(Pm.shape[1])
+    y = torch.empty(Pm.shape[0], dtype=torch.float64, device=DEV)
+    ops.csr_spmv(dM, dev(x), y)
+    assert np.array_equal(y.cpu().numpy(), K.spmv(Pm, x, np.zeros(Pm.shape[0]), 1.0, 0.0))
+    # ... and with the maps switched off the packed CSR runs as before
+    try:
+        ops.set_grid_maps_enabled(False)
+        dM = ops.DeviceCSR.from_scipy(Pm, DEV)
+        assert isinstance(dM.pack(), ops.PackedCSR) and dM.patterns is None
+    finally:
+        ops.set_grid_maps_enabled(True)
+
+
 def test_row_patterns_are_refused_when_rows_do_not_repeat():
-    for name in ("val64_col16_jittered", "val8_col16_prolong", "val16_col16_ragged"):
+    for name in ("val64_col16_jittered", "val16_col16_ragged"):
         dA = ops.DeviceCSR.from_scipy(packed_case(name), DEV)
         Pk = dA.pack()
         assert dA.patterns is None and isinstance(Pk, ops.PackedCSR), name

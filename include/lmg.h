@@ -168,6 +168,25 @@ int lmg_stencil_sweep(int mode, int64_t n, int32_t line_stride, const uint8_t *d
                       const double *d_b, double *d_out, double alpha, double beta, double *d_partials,
                       double *d_norm2, void *stream);
 
+/* Fused smoothing pass on a grid-stencil matrix (same format arguments as lmg_stencil_sweep):
+ *     x_out = J^sweeps(x_in),  J(x) = x + omega * D^-1 (b - A x),   sweeps = 1..3,
+ *     r_out = b - A x_out      (d_r_out may be NULL),
+ * i.e. the `smooth_steps` sweeps of Multigrid.py:88 / :121 and the residual of :90 in ONE pass over
+ * x_in, b and the pattern ids (temporal blocking in registers: a wave marches down a 128-column strip
+ * with all intermediate iterates in registers, see csrc/stencil_fused.hip).  d_x_in == NULL means a zero
+ * initial iterate (coarse levels, Multigrid.py:103): the first sweep then is omega * (D^-1 b), the bits
+ * of lmg_vmul.  hot_pattern / h_hot_val (HOST pointer to its 9 slot values; -1 / NULL: none) name a
+ * pattern that has every slot of union_mask and a non-zero diagonal -- the interior row of a grid
+ * operator: lines on which all lanes of a wave hold it run with its values in scalar registers.  Every
+ * value equals the one the separate lmg_stencil_sweep launches produce, bit for bit.  x_out (and
+ * r_out) must not alias x_in.  Compiled for the union masks lmg_stencil_smooth_supported accepts
+ * (5-point 0x0BA, 9-point 0x1FF, 1-D 0x038); LMG_ERR_CAPACITY for others (run the separate sweeps). */
+int lmg_stencil_smooth_supported(uint32_t union_mask);
+int lmg_stencil_smooth(int64_t n, int32_t line_stride, const uint8_t *d_pid, int32_t npat,
+                       const double *d_st_val, const int32_t *d_st_mask, uint32_t union_mask,
+                       int32_t hot_pattern, const double *h_hot_val, int sweeps, const double *d_x_in,
+                       const double *d_b, double omega, double *d_x_out, double *d_r_out, void *stream);
+
 /* ---- sliced-ELL ("SELL-64") sweeps: matrices with long rows ---------------------------
  * Third lossless twin.  Slice s = rows 64 s .. 64 s + 63, padded to its longest row
  * d_slice_len[s]; entry j of row r lives at d_slice_base[s] + 64 j + (r mod 64) of d_col

@@ -1,0 +1,473 @@
+// Fused smoothing passes on grid-stencil matrices (format of stencil.hip) for gfx950:
+//     x_out = J^S(x_in)              S = 1..3 weighted-Jacobi sweeps x <- x + omega * D^-1 (b - A x)
+//     r     = b - A x_out            (optional: the residual the cycle restricts next, Multigrid.py:90)
+// in ONE pass over x_in, b and the pattern ids -- 25 B/row (+8 with r) for up to four operator
+// applications instead of 25 B/row each.  The S sweeps of Multigrid.py:88 / :121 are separate launches of
+// stencil_sweep_kernel otherwise; the arithmetic per row and per sweep is the same instruction sequence,
+// so every value is bit-identical to the unfused sequence (tests assert array_equal).
+//
+// Temporal blocking without LDS and without barriers: one WAVE owns a strip of 128 consecutive linear
+// indices per grid line (two per lane, 16-byte loads / stores) and marches down a segment of lines with
+// all intermediate iterates in registers:
+//     step t:  line t of x_in, b, ids arrives (issued PF steps earlier),
+//              x^1 line t-1 from x^0 lines t-2..t,  x^2 line t-2 from x^1 lines t-3..t-1, ...,
+//              x^S line t-S is stored,  r line t-S-1 from x^S lines t-S-2..t-S is stored.
+// Left / right neighbours come from the neighbouring lanes (DPP wave shifts); the window edges are
+// simply wrong after each sweep, which is why a strip only STORES its inner 128 - 2H columns and a
+// segment its inner lines (H = S, +1 with the residual): strips overlap by 2H columns, segments by 2H
+// lines (redundant loads and arithmetic, a few per cent).  Everything is expressed in linear indices
+// i = line * W + column, exactly like the format itself: a "column" outside [0, W) is just the linear
+// neighbour in the adjacent line, so no grid geometry is assumed beyond the pattern offsets c*W + d.
+#include <string.h>
+#include "lmg_common.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / LMG_WAVE;
+constexpr int kMaxPat = 64;
+constexpr int kStripCols = 2 * LMG_WAVE;      // linear indices per line and wave
+constexpr unsigned kMask5 = 0x0BAu;           // slots {-W, -1, 0, +1, +W}
+constexpr unsigned kMask9 = 0x1FFu;           // full 3x3
+constexpr unsigned kMask1D = 0x038u;          // {-1, 0, +1}
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+struct __attribute__((aligned(8))) d2u { double a, b; };
+
+struct MArgs {
+    int n;
+    int W;
+    int lines;                // ceil(n / W)
+    int npat;
+    unsigned umask;
+    int strips, segs, seg_lines;
+    const unsigned char *pid;
+    const double *st_val;
+    const int *st_mask;
+    const double *x;          // may be NULL with ZERO
+    const double *b;
+    double *out;
+    double *r;                // may be NULL without RESID
+    double omega;
+    int hot;                  // most frequent pattern with all union slots and a diagonal, or -1
+    double hot_val[9];        // its values by slot (scalar registers in the kernel)
+    double hot_rdiag;         // 1 / its diagonal
+};
+
+__device__ __forceinline__ double dpp_lower(double src)      // lane i <- lane i-1, lane 0 <- 0
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_upper(double src)      // lane i <- lane i+1, lane 63 <- 0
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ d2 load2(const double *__restrict__ v, int64_t i, int n)
+{
+    d2 r;
+    if (i >= 0 && i + 1 < n) {
+        const d2u t = *reinterpret_cast<const d2u *>(v + i);
+        r.x = t.a;
+        r.y = t.b;
+    } else {
+        r.x = (i >= 0 && i < n) ? v[i] : 0.0;
+        r.y = (i + 1 >= 0 && i + 1 < n) ? v[i + 1] : 0.0;
+    }
+    return r;
+}
+
+// One line of input as it comes out of memory.  Every step issues EXACTLY the same vector-memory
+// instructions (three loads from clamped addresses, two -- with the residual four -- buffer stores whose
+// disabled lanes point out of range), none of them inside a branch, and nothing is computed from a load's
+// result until the line is consumed PF steps later.  gfx950 counts loads and stores in ONE in-order
+// counter (vmcnt): a load or store issued on only one side of a branch makes the compiler wait for the
+// smaller of the two counts after the join, i.e. for loads that were meant to stay in flight, and the wave
+// serialises on the memory latency once per line (measured: 0.157 -> see DESIGN.md).
+struct Line {
+    d2 x, b;
+    int praw;       // the two pattern ids as loaded (16 bits)
+    int ok;         // bit 0 / 1: element 0 / 1 is a row of the matrix; bit 2 / 3: the pair was clamped
+                    // up (i == -1) / down (i == n-1) and holds the wanted element in the other half
+};
+
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+constexpr unsigned kOOB = 0xFFFFFFF0u;        // buffer offset beyond any num_records: the access is dropped
+
+// window of one line for the two elements of a lane: [0] = x[. - 1], [1], [2] = the lane's own two, [3] = x[. + 2]
+template <bool SIDES>
+__device__ __forceinline__ void window(const d2 &c, double (&w)[4])
+{
+    w[1] = c.x;
+    w[2] = c.y;
+    if (SIDES) {
+        w[0] = dpp_lower(c.y);
+        w[3] = dpp_upper(c.x);
+    } else {
+        w[0] = w[3] = 0.0;
+    }
+}
+
+// A x for the two elements of a lane on one line, per-lane patterns: slot order = column order
+template <unsigned UM>
+__device__ __forceinline__ void apply_rows(const double *s_val, int pA, int pB, int mA, int mB,
+                                           const d2 &u, const d2 &c, const d2 &d, double &accA, double &accB)
+{
+    constexpr bool DIAG = (UM & 0x145u) != 0;
+    double wu[4], wc[4], wd[4];
+    window<true>(c, wc);
+    window<DIAG>(u, wu);
+    window<DIAG>(d, wd);
+    accA = 0.0;
+    accB = 0.0;
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        if (!((UM >> s) & 1u)) continue;                           // compile time
+        const int cc = s / 3, dd = s % 3;
+        const double *w = cc == 0 ? wu : (cc == 1 ? wc : wd);
+        const double vA = s_val[pA * 9 + s], vB = s_val[pB * 9 + s];
+        const double tA = accA + vA * w[dd], tB = accB + vB * w[dd + 1];
+        accA = ((mA >> s) & 1) ? tA : accA;
+        accB = ((mB >> s) & 1) ? tB : accB;
+    }
+}
+
+// The same for a line on which every lane holds the HOT pattern (the most frequent one, all union slots
+// present): its values sit in scalar registers, no LDS reads, no selects -- the same products and sums
+// in the same order, hence the same bits.
+template <unsigned UM>
+__device__ __forceinline__ void apply_rows_hot(const double (&hv)[9], const d2 &u, const d2 &c,
+                                               const d2 &d, double &accA, double &accB)
+{
+    constexpr bool DIAG = (UM & 0x145u) != 0;
+    double wu[4], wc[4], wd[4];
+    window<true>(c, wc);
+    window<DIAG>(u, wu);
+    window<DIAG>(d, wd);
+    accA = 0.0;
+    accB = 0.0;
+#pragma unroll
+    for (int s = 0; s < 9; ++s) {
+        if (!((UM >> s) & 1u)) continue;                           // compile time
+        const int cc = s / 3, dd = s % 3;
+        const double *w = cc == 0 ? wu : (cc == 1 ? wc : wd);
+        accA = accA + hv[s] * w[dd];
+        accB = accB + hv[s] * w[dd + 1];
+    }
+}
+
+constexpr int kUF = 6;          // steps per loop iteration = period of all register rings
+constexpr int kNBR = 6;         // depth of the b / id rings (>= S + 2)
+
+// UM: the union slot mask of the matrix, compile time (5-point, 9-point, 1-D chain: anything else runs
+// the separate sweeps) -- a run-time mask costs a scalar branch per slot, stage and line.
+template <int S, unsigned UM, bool RESID, bool ZERO, int PF>
+__global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
+{
+    static_assert(kUF % 3 == 0 && kUF % kNBR == 0 && kUF % PF == 0 && S + 2 <= kNBR, "ring periods");
+    constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);      // halo in lines and columns
+    __shared__ double s_val[kMaxPat * 9];
+    __shared__ int s_mask[kMaxPat];
+    __shared__ double s_rdiag[kMaxPat];
+
+    const int t_ = threadIdx.x;
+    for (int i = t_; i < a.npat * 9; i += kBlock) s_val[i] = a.st_val[i];
+    for (int i = t_; i < a.npat; i += kBlock) {
+        const int m = a.st_mask[i];
+        const double dg = (m & 16) ? a.st_val[i * 9 + 4] : 0.0;
+        s_rdiag[i] = dg != 0.0 ? 1.0 / dg : 0.0;
+        s_mask[i] = dg == 0.0 ? (m | (1 << 16)) : m;             // bit 16: no usable diagonal -> copy x
+    }
+    __syncthreads();
+
+    const int lane = t_ & (LMG_WAVE - 1);
+    const int item = (int)blockIdx.x * kWavesPerBlock + (t_ >> 6);
+    if (item >= a.strips * a.segs) return;
+    const int seg = item / a.strips, strip = item - seg * a.strips;
+    constexpr int U = kStripCols - 2 * H;                        // columns a strip stores
+    const int n = a.n;
+    const int64_t W = a.W;
+    const int c0 = strip * U - H;                                // linear-index offset of lane 0's first element
+    const int out_y0 = seg * a.seg_lines, out_y1 = min(a.lines, out_y0 + a.seg_lines);
+    const int y_begin = out_y0 - H, y_end = out_y1 + H;          // lines loaded: [y_begin, y_end)
+    const int cidx = 2 * lane;                                   // window column of element 0
+    // columns this lane may store (element 0 / 1): inside the strip's inner part and inside the line
+    const bool colA = cidx >= H && cidx < kStripCols - H && c0 + cidx < W;
+    const bool colB = cidx + 1 >= H && cidx + 1 < kStripCols - H && c0 + cidx + 1 < W;
+    const double omega = a.omega;
+    // hot pattern: id on both elements + both marked as rows; -1 (no hot pattern) never matches
+    const int hot2 = a.hot >= 0 ? (a.hot | (a.hot << 8) | (3 << 16)) : -1;
+    double hv[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) hv[s] = a.hot_val[s];
+    const double hrd = a.hot_rdiag;
+
+    auto fetch = [&](int y, Line &L) {
+        const bool line_ok = y >= 0 && y < a.lines && y < y_end;             // wave-uniform, no branch on it
+        const int yc = min(max(y, 0), a.lines - 1);
+        const int64_t i = (int64_t)yc * W + c0 + cidx;
+        const bool okA = line_ok && i >= 0 && i < n, okB = line_ok && i + 1 >= 0 && i + 1 < n;
+        const int64_t j = min(max(i, (int64_t)0), (int64_t)n - 2);           // always a valid pair (n >= 2)
+        L.ok = (okA ? 1 : 0) | (okB ? 2 : 0) | (i == -1 ? 4 : 0) | (i == (int64_t)n - 1 ? 8 : 0);
+        unsigned short two;
+        __builtin_memcpy(&two, a.pid + j, 2);
+        L.praw = (int)two;
+        const d2u bb = *reinterpret_cast<const d2u *>(a.b + j);
+        L.b.x = bb.a;
+        L.b.y = bb.b;
+        if (!ZERO) {
+            const d2u xx = *reinterpret_cast<const d2u *>(a.x + j);
+            L.x.x = xx.a;
+            L.x.y = xx.b;
+        } else {
+            L.x.x = L.x.y = 0.0;
+        }
+    };
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)n * 8u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(RESID ? a.r : a.out, 0, (int)((unsigned)n * 8u), 0x00020000);
+    auto store2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, int p2, double va, double vb) {
+        const bool yok = y >= out_y0 && y < out_y1;
+        const int64_t i = (int64_t)y * W + c0 + cidx;
+        const bool stA = yok && colA && ((p2 >> 16) & 1), stB = yok && colB && ((p2 >> 17) & 1);
+        u4 v4;
+        v4.x = (unsigned)__double2loint(va);
+        v4.y = (unsigned)__double2hiint(va);
+        v4.z = (unsigned)__double2loint(vb);
+        v4.w = (unsigned)__double2hiint(vb);
+        __builtin_amdgcn_raw_buffer_store_b128(v4, rs, (stA && stB) ? (unsigned)i * 8u : kOOB, 0, 0);
+        u2 v2;
+        v2.x = stA ? v4.x : v4.z;
+        v2.y = stA ? v4.y : v4.w;
+        __builtin_amdgcn_raw_buffer_store_b64(v2, rs, (stA != stB) ? (unsigned)(stA ? i : i + 1) * 8u : kOOB, 0, 0);
+    };
+
+    // Register rings, all indexed with compile-time slots inside the unrolled block of kUF steps:
+    // line L of iterate s lives in X[s][L mod 3], its b / ids / "all lanes hot" flag in slot L mod kNBR
+    // (phases relative to the first step of a block, which is a multiple of kUF lines after y_begin).
+    d2 X[S + 1][3];
+    d2 Bq[kNBR];
+    int Pq[kNBR];
+    bool Hq[kNBR];
+    const d2 zero2 = {0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s <= S; ++s) X[s][0] = X[s][1] = X[s][2] = zero2;
+#pragma unroll
+    for (int k = 0; k < kNBR; ++k) {
+        Bq[k] = zero2;
+        Pq[k] = 0;
+        Hq[k] = false;
+    }
+
+    Line pre[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) fetch(y_begin + u, pre[u]);
+
+    const int t_last = out_y1 - 1 + S + (RESID ? 1 : 0);         // last step that still produces output
+    for (int tb = y_begin; tb <= t_last; tb += kUF) {
+#pragma unroll
+        for (int u = 0; u < kUF; ++u) {
+            const int t = tb + u;
+            // ---- line t arrives ------------------------------------------------------------------
+            const int q0 = u % kNBR;
+            {
+                const Line &L = pre[u % PF];
+                const bool okA = L.ok & 1, okB = L.ok & 2, up = L.ok & 4, down = L.ok & 8;
+                d2 bv, xv;
+                // (selects that only do something in the first / last lines of the matrix)
+                bv.x = okA ? (down ? L.b.y : L.b.x) : 0.0;
+                bv.y = okB ? (up ? L.b.x : L.b.y) : 0.0;
+                xv.x = okA ? (down ? L.x.y : L.x.x) : 0.0;
+                xv.y = okB ? (up ? L.x.x : L.x.y) : 0.0;
+                const int pa = down ? (L.praw >> 8) & 0xff : L.praw & 0xff, pb = up ? L.praw & 0xff : (L.praw >> 8) & 0xff;
+                Bq[q0] = bv;
+                X[0][u % 3] = xv;
+                Pq[q0] = (okA ? pa : 0) | ((okB ? pb : 0) << 8) | ((L.ok & 3) << 16);
+                Hq[q0] = __all(Pq[q0] == hot2);
+            }
+            fetch(t + PF, pre[u % PF]);
+            // ---- stages 1..S: iterate s on line t - s -----------------------------------------------
+#pragma unroll
+            for (int s = 1; s <= S; ++s) {
+                const int q = ((u - s) % kNBR + kNBR) % kNBR;                 // ring slot of line t - s
+                const int xm = ((u - s - 1) % 3 + 3) % 3, xc = ((u - s) % 3 + 3) % 3, xp = ((u - s + 1) % 3 + 3) % 3;
+                const int p2 = Pq[q];
+                const d2 bq = Bq[q];
+                d2 nx;
+                if (Hq[q]) {                                                 // wave-uniform
+                    if (ZERO && s == 1) {
+                        nx.x = omega * (hrd * bq.x);
+                        nx.y = omega * (hrd * bq.y);
+                    } else {
+                        double accA, accB;
+                        apply_rows_hot<UM>(hv, X[s - 1][xm], X[s - 1][xc], X[s - 1][xp], accA, accB);
+                        nx.x = X[s - 1][xc].x + omega * (hrd * (bq.x - accA));
+                        nx.y = X[s - 1][xc].y + omega * (hrd * (bq.y - accB));
+                    }
+                } else {
+                    const int pA = p2 & 0xff, pB = (p2 >> 8) & 0xff;
+                    const int mA = s_mask[pA], mB = s_mask[pB];
+                    if (ZERO && s == 1) {
+                        // first sweep from a zero iterate: x = omega * (D^-1 b)  (lmg_vmul's bits)
+                        nx.x = omega * (s_rdiag[pA] * bq.x);
+                        nx.y = omega * (s_rdiag[pB] * bq.y);
+                    } else {
+                        double accA, accB;
+                        apply_rows<UM>(s_val, pA, pB, mA, mB, X[s - 1][xm], X[s - 1][xc], X[s - 1][xp], accA, accB);
+                        const double xa = X[s - 1][xc].x, xb = X[s - 1][xc].y;
+                        const double rA = bq.x - accA, rB = bq.y - accB;
+                        nx.x = (mA >> 16) ? xa : xa + omega * (s_rdiag[pA] * rA);
+                        nx.y = (mB >> 16) ? xb : xb + omega * (s_rdiag[pB] * rB);
+                    }
+                    // elements that are no rows of the matrix stay zero (nothing valid ever reads them)
+                    if (!((p2 >> 16) & 1)) nx.x = 0.0;
+                    if (!((p2 >> 17) & 1)) nx.y = 0.0;
+                }
+                X[s][xc] = nx;
+                if (s == S) store2(rs_out, t - S, p2, nx.x, nx.y);
+            }
+            // ---- residual of the final iterate on line t - S - 1 ---------------------------------------
+            if (RESID) {
+                const int y = t - S - 1;
+                const int q = ((u - S - 1) % kNBR + kNBR) % kNBR;
+                const int xm = ((u - S - 2) % 3 + 3) % 3, xc = ((u - S - 1) % 3 + 3) % 3, xp = ((u - S) % 3 + 3) % 3;
+                const int p2 = Pq[q];
+                double accA, accB;
+                if (Hq[q]) {
+                    apply_rows_hot<UM>(hv, X[S][xm], X[S][xc], X[S][xp], accA, accB);
+                } else {
+                    const int pA = p2 & 0xff, pB = (p2 >> 8) & 0xff;
+                    apply_rows<UM>(s_val, pA, pB, s_mask[pA], s_mask[pB], X[S][xm], X[S][xc], X[S][xp], accA, accB);
+                }
+                store2(rs_r, y, p2, Bq[q].x - accA, Bq[q].y - accB);
+            }
+        }
+    }
+}
+
+int g_fused_seg_lines = 0;      // 0 = chosen per launch
+int g_fused_pf = 0;             // 0 = default
+
+template <int S, unsigned UM, bool RESID, bool ZERO>
+int launch4(MArgs a, hipStream_t st)
+{
+    constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);
+    constexpr int U = kStripCols - 2 * H;
+    a.strips = (a.W + U - 1) / U;
+    // segments: enough waves to fill the chip (256 CUs x 16 waves), but no shorter than 4 H lines
+    int seg_lines = g_fused_seg_lines;
+    if (seg_lines <= 0) {
+        const int want_segs = (4096 + a.strips - 1) / a.strips;
+        seg_lines = (a.lines + want_segs - 1) / want_segs;
+        const int floor_lines = H > 0 ? 4 * H : 4;
+        if (seg_lines < floor_lines) seg_lines = floor_lines;
+    }
+    a.seg_lines = seg_lines;
+    a.segs = (a.lines + seg_lines - 1) / seg_lines;
+    const int items = a.strips * a.segs;
+    const int grid = (items + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (g_fused_pf == 3)
+        hipLaunchKernelGGL((stencil_fused_kernel<S, UM, RESID, ZERO, 3>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
+    else
+        hipLaunchKernelGGL((stencil_fused_kernel<S, UM, RESID, ZERO, 2>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+template <int S, unsigned UM>
+int launch2(MArgs a, bool resid, bool zero, hipStream_t st)
+{
+    if (resid) return zero ? launch4<S, UM, true, true>(a, st) : launch4<S, UM, true, false>(a, st);
+    return zero ? launch4<S, UM, false, true>(a, st) : launch4<S, UM, false, false>(a, st);
+}
+
+template <unsigned UM>
+int launch1(MArgs a, int sweeps, bool resid, bool zero, hipStream_t st)
+{
+    switch (sweeps) {
+    case 1: return launch2<1, UM>(a, resid, zero, st);
+    case 2: return launch2<2, UM>(a, resid, zero, st);
+    default: return launch2<3, UM>(a, resid, zero, st);
+    }
+}
+
+}  // namespace
+
+int lmg_fused_tune_set(const char *key, int v)
+{
+    if (strcmp(key, "fused_seg_lines") == 0) {
+        if (v < 0) return LMG_ERR_ARG;
+        g_fused_seg_lines = v;
+        return LMG_OK;
+    }
+    if (strcmp(key, "fused_pf") == 0) {
+        if (v != 0 && v != 2 && v != 3) return LMG_ERR_ARG;
+        g_fused_pf = v;
+        return LMG_OK;
+    }
+    return LMG_ERR_ARG;
+}
+int lmg_fused_tune_get(const char *key)
+{
+    if (strcmp(key, "fused_seg_lines") == 0) return g_fused_seg_lines;
+    if (strcmp(key, "fused_pf") == 0) return g_fused_pf;
+    return LMG_ERR_ARG;
+}
+
+extern "C" {
+
+int lmg_stencil_smooth(int64_t n, int32_t line_stride, const uint8_t *pid, int32_t npat, const double *st_val,
+                       const int32_t *st_mask, uint32_t union_mask, int32_t hot_pattern, const double *h_hot_val,
+                       int sweeps, const double *x_in, const double *b, double omega, double *x_out, double *r_out,
+                       void *stream)
+{
+    if (n < 0 || n >= (1ll << 29) - 4096 || npat < 1 || npat > kMaxPat || (union_mask & ~0x1FFu)) return LMG_ERR_ARG;   // 32-bit byte offsets
+    if (sweeps < 1 || sweeps > 3) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    if (n < 2) return LMG_ERR_CAPACITY;
+    if (!pid || !st_val || !st_mask || !b || !x_out || x_in == x_out || r_out == x_out || (r_out && r_out == x_in))
+        return LMG_ERR_ARG;
+    if (line_stride < 3 || line_stride > n) return LMG_ERR_ARG;
+    MArgs a;
+    a.n = (int)n;
+    a.W = line_stride;
+    a.lines = (int)((n + line_stride - 1) / line_stride);
+    a.npat = npat;
+    a.umask = union_mask;
+    a.strips = a.segs = a.seg_lines = 0;
+    a.pid = pid;
+    a.st_val = st_val;
+    a.st_mask = st_mask;
+    a.x = x_in;
+    a.b = b;
+    a.out = x_out;
+    a.r = r_out;
+    a.omega = omega;
+    a.hot = -1;
+    for (int k = 0; k < 9; ++k) a.hot_val[k] = 0.0;
+    a.hot_rdiag = 0.0;
+    if (hot_pattern >= 0 && hot_pattern < npat && h_hot_val && h_hot_val[4] != 0.0) {
+        a.hot = hot_pattern;
+        for (int k = 0; k < 9; ++k) a.hot_val[k] = h_hot_val[k];
+        a.hot_rdiag = 1.0 / h_hot_val[4];
+    }
+    hipStream_t st = lmg_stream(stream);
+    const bool resid = r_out != nullptr, zero = x_in == nullptr;
+    switch (union_mask) {
+    case kMask5: return launch1<kMask5>(a, sweeps, resid, zero, st);
+    case kMask9: return launch1<kMask9>(a, sweeps, resid, zero, st);
+    case kMask1D: return launch1<kMask1D>(a, sweeps, resid, zero, st);
+    default: return LMG_ERR_CAPACITY;        // other slot sets: run the separate sweeps
+    }
+}
+
+int lmg_stencil_smooth_supported(uint32_t union_mask)
+{
+    return union_mask == kMask5 || union_mask == kMask9 || union_mask == kMask1D;
+}
+
+}  // extern "C"

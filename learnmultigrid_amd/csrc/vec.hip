@@ -13,6 +13,8 @@ int lmg_rpat_nt_set(int v);
 int lmg_rpat_nt_get(void);
 int lmg_stencil_tune_set(const char *key, int v);
 int lmg_stencil_tune_get(const char *key);
+int lmg_fused_tune_set(const char *key, int v);
+int lmg_fused_tune_get(const char *key);
 int lmg_gs_tune_set(int v);
 int lmg_gs_tune_get(void);
 
@@ -242,6 +244,7 @@ int lmg_tune_set(const char *key, int value)
     if (strcmp(key, "rpat_variant") == 0) return lmg_rpat_tune_set(value);
     if (strcmp(key, "rpat_nt_rows") == 0) return lmg_rpat_nt_set(value);
     if (strncmp(key, "stencil_", 8) == 0) return lmg_stencil_tune_set(key, value);
+    if (strncmp(key, "fused_", 6) == 0) return lmg_fused_tune_set(key, value);
     if (strcmp(key, "gs_single_max") == 0) return lmg_gs_tune_set(value);
     return LMG_ERR_ARG;
 }
@@ -254,6 +257,7 @@ int lmg_tune_get(const char *key)
     if (strcmp(key, "rpat_variant") == 0) return lmg_rpat_tune_get();
     if (strcmp(key, "rpat_nt_rows") == 0) return lmg_rpat_nt_get();
     if (strncmp(key, "stencil_", 8) == 0) return lmg_stencil_tune_get(key);
+    if (strncmp(key, "fused_", 6) == 0) return lmg_fused_tune_get(key);
     if (strcmp(key, "gs_single_max") == 0) return lmg_gs_tune_get();
     return LMG_ERR_ARG;
 }

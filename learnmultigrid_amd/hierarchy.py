@@ -189,6 +189,25 @@ class Hierarchy:
         else:
             raise ValueError("unknown smoother %r" % (smoother,))
 
+    def _fusable(self, l, smoother, steps):
+        avail = getattr(self.ops, "stencil_smooth_available", None)
+        return (smoother == "Jacobi" and steps >= 1 and avail is not None and avail(self.levels[l].A))
+
+    def smooth_fused(self, l, steps, omega, x_is_zero=False, want_residual=False):
+        """`steps` Jacobi sweeps on level l (and r = b - A x afterwards) as fused passes of at most
+        FUSED_MAX_SWEEPS sweeps each (lmg_stencil_smooth): same bits as smooth() + the residual launch,
+        a third of the passes over the level's vectors."""
+        lev = self.levels[l]
+        left = steps
+        mx = self.ops.FUSED_MAX_SWEEPS
+        while left > 0:
+            k = min(left, mx)
+            left -= k
+            self.ops.stencil_smooth(lev.A, None if x_is_zero else lev.x, lev.b, omega, k, lev.tmp,
+                                    lev.r if (want_residual and left == 0) else None)
+            lev.x, lev.tmp = lev.tmp, lev.x
+            x_is_zero = False
+
     def coarse_solve(self):
         lev = self.levels[-1]
         self.coarse.apply(lev.b, lev.x)
@@ -203,17 +222,26 @@ class Hierarchy:
         right-hand side (Multigrid.py:77-124).  depth = number of grids used."""
         last = (len(self.levels) if depth is None else depth) - 1
         lev, nxt = self.levels[l], self.levels[l + 1]
-        self.smooth(l, smoother, steps, omega, gs_mode, x_is_zero)            # :88
-        if after_presmooth is not None:
-            after_presmooth(lev.x)
-        self.ops.csr_residual_norm2(lev.A, lev.x, lev.b, lev.r, None, None)        # :90
+        fused = self._fusable(l, smoother, steps)
+        if fused:
+            self.smooth_fused(l, steps, omega, x_is_zero, want_residual=True)  # :88 + :90 in one pass
+            if after_presmooth is not None:
+                after_presmooth(lev.x)
+        else:
+            self.smooth(l, smoother, steps, omega, gs_mode, x_is_zero)            # :88
+            if after_presmooth is not None:
+                after_presmooth(lev.x)
+            self.ops.csr_residual_norm2(lev.A, lev.x, lev.b, lev.r, None, None)        # :90
         self.ops.csr_spmv(lev.R, lev.r, nxt.b, 1.0, 0.0)                           # :93
         if l + 1 == last:
             self.coarse_solve()                                               # :106
         else:
             self.cycle(smoother, steps, omega, gs_mode, l + 1, depth, x_is_zero=True)   # zeros, :103
         self.ops.csr_spmv(lev.P, nxt.x, lev.x, 1.0, 1.0)                           # :115
-        self.smooth(l, smoother, steps, omega, gs_mode)                       # :121
+        if fused:
+            self.smooth_fused(l, steps, omega)                                # :121
+        else:
+            self.smooth(l, smoother, steps, omega, gs_mode)                       # :121
 
     def residual_norm(self, want_vector=True):
         """||b - A x||_2 on the fine level (Multigrid.py:62-63); one 8-byte D2H copy."""

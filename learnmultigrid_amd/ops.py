@@ -445,7 +445,7 @@ class StencilTwin:
     -- a few hundred numbers --; the per-row pattern ids are shared with the RowPatterns twin.
     from_patterns returns None for everything that does not fit (the RPAT kernel then runs)."""
 
-    __slots__ = ("n", "W", "npat", "pid", "st_val", "st_mask", "umask", "bytes_", "patterns")
+    __slots__ = ("n", "W", "npat", "pid", "st_val", "st_mask", "umask", "bytes_", "patterns", "hot", "_hot_val")
 
     @staticmethod
     def _decompose(off, W):
@@ -501,6 +501,14 @@ class StencilTwin:
         self.st_mask = torch.from_numpy(st_mask).to(dev)
         self.umask = int(np.bitwise_or.reduce(st_mask)) if R.npat else 0
         self.bytes_ = R.n + 76 * R.npat
+        # hot pattern for the fused smoothing pass: the most frequent one among those that have every
+        # union slot and a non-zero diagonal (the interior row of a grid operator)
+        self.hot, self._hot_val = -1, None
+        cand = [p for p in range(R.npat) if st_mask[p] == self.umask and (st_mask[p] & 16) and st_val[p * 9 + 4] != 0.0]
+        if cand:
+            counts = torch.bincount(R.pid.long(), minlength=R.npat).cpu().numpy() if len(cand) > 1 else None
+            self.hot = int(cand[0] if counts is None else max(cand, key=lambda p: counts[p]))
+            self._hot_val = (ctypes.c_double * 9)(*[float(v) for v in st_val[self.hot * 9: self.hot * 9 + 9]])
         return self
 
     def bytes(self):
@@ -529,6 +537,40 @@ def _stencil(mode, S, x, b, out, alpha, beta, partials, norm2):
     return _lib.lib().lmg_stencil_sweep(mode, S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask,
                                         _p(x), _p(b), _p(out), float(alpha), float(beta), _p(partials), _p(norm2),
                                         _s())
+
+
+FUSED_MAX_SWEEPS = 3
+
+
+def stencil_smooth_available(A):
+    """True when `A` has a grid-stencil twin, i.e. stencil_smooth can run its smoothing passes fused."""
+    S = getattr(A, "stencil", None)
+    return bool(_PACKED_ENABLED and _STENCIL_ENABLED and _FUSED_ENABLED and S is not None
+                and _lib.lib().lmg_stencil_smooth_supported(S.umask))
+
+
+_FUSED_ENABLED = True
+
+
+def set_fused_enabled(flag):
+    """Whether Hierarchy.smooth may fuse the Jacobi sweeps of a level visit (default) or launches them
+    one by one (A/B runs and parity tests)."""
+    global _FUSED_ENABLED
+    _FUSED_ENABLED = bool(flag)
+
+
+def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None):
+    """x_out = `sweeps` (1..3) weighted-Jacobi sweeps from x_in (None = zero iterate), r_out = b - A x_out
+    (optional), in one pass (lmg_stencil_smooth); same bits as the separate csr_jacobi / vmul /
+    csr_residual_norm2 launches."""
+    _vec_ok(x_in, b, x_out, r_out)
+    S = A.stencil
+    if S is None:
+        raise LmgError("stencil_smooth needs a grid-stencil matrix")
+    hv = None if S._hot_val is None else ctypes.addressof(S._hot_val)
+    check(_lib.lib().lmg_stencil_smooth(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask, S.hot, hv,
+                                        int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out), _p(r_out), _s()),
+          "lmg_stencil_smooth")
 
 
 def _use_stencil(A, *vecs):

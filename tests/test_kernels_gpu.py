@@ -865,6 +865,44 @@ def test_row_pattern_sweeps_bit_exact(name, variant, nt):
         ops.tune_set("stencil_nt_rows", nt_default)
 
 
+@pytest.mark.parametrize("name", ["poisson2d_129", "poisson1d", "galerkin_9pt", "with_empty_and_diagless_rows",
+                                  "poisson2d_300"])
+@pytest.mark.parametrize("seg_lines,pf", [(0, 0), (4, 2), (7, 3), (1000, 2)])
+def test_fused_stencil_smoothing_equals_separate_sweeps(name, seg_lines, pf):
+    """lmg_stencil_smooth (S sweeps [+ residual] in one pass, iterates in registers) against the oracle's
+    separate Jacobi sweeps and residual, bitwise, for S = 1..3, zero / non-zero initial iterate, with and
+    without the residual, few and many line segments per strip."""
+    A = K.as_csr(P.poisson_2d_structured(299)[0]) if name == "poisson2d_300" else rpat_case(name)
+    n = A.shape[0]
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    dA.pack()
+    assert ops.stencil_smooth_available(dA)
+    rng = np.random.default_rng(77)
+    x0, b = rng.standard_normal(n), rng.standard_normal(n)
+    try:
+        ops.tune_set("fused_seg_lines", seg_lines)
+        ops.tune_set("fused_pf", pf)
+        for omega in (0.8, 1.0):
+            for zero in (False, True):
+                want = np.zeros(n) if zero else x0.copy()
+                for S in (1, 2, 3):
+                    want = K.jacobi(A, want, b, omega)
+                    wr, _ = K.residual(A, want, b)
+                    for resid in (False, True):
+                        out = torch.full((n,), np.nan, dtype=torch.float64, device=DEV)
+                        r = torch.full((n,), np.nan, dtype=torch.float64, device=DEV) if resid else None
+                        ops.stencil_smooth(dA, None if zero else dev(x0), dev(b), omega, S, out, r)
+                        got = out.cpu().numpy()
+                        assert not np.isnan(got).any(), (name, S, zero, resid)
+                        # (a zero iterate and b_i = -0.0 would differ in the sign of zero only; b is random)
+                        assert np.array_equal(got, want), (name, omega, S, zero, resid, np.flatnonzero(got != want)[:8])
+                        if resid:
+                            assert np.array_equal(r.cpu().numpy(), wr), (name, omega, S, zero)
+    finally:
+        ops.tune_set("fused_seg_lines", 0)
+        ops.tune_set("fused_pf", 0)
+
+
 def test_row_pattern_sweeps_full_size_4097_bit_exact_vs_oracle():
     """The instantiations the headline bench times -- stencil_sweep_kernel<JACOBI|RESIDUAL, NT = true> on
     the 16.8 M-row fine level of cfg#4 (and rpat_sweep_kernel<.., 5, 2, NT = true>, its fallback) --

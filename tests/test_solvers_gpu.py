@@ -177,6 +177,36 @@ def test_cfg2_513_three_levels_jacobi_and_graph_replay():
     assert np.array_equal(mg2.get_solution(), mg.get_solution())
 
 
+@pytest.mark.parametrize("m,levels", [(128, 4), (512, 3)])
+@pytest.mark.parametrize("steps", [1, 2, 3, 4, 7])
+def test_fused_smoothing_passes_equal_separate_sweeps(m, levels, steps):
+    """The cycle with its Jacobi sweeps (and the residual) fused into single passes (lmg_stencil_smooth,
+    chunks of <= 3 sweeps) against the same cycle with one launch per sweep: identical histories and
+    iterates, eager and replayed from a hipGraph."""
+    from learnmultigrid_amd import ops
+    A, rhs = P.poisson_2d_structured(m)
+    hier = P.geometric_hierarchy_2d(m + 1, levels)
+    kw = dict(levels=levels, smoother="Jacobi", smooth_steps=steps, max_iterations=6, error=1e-30,
+              smoother_semantics="as_named", omega=0.8)
+    runs = {}
+    try:
+        for fused in (False, True):
+            ops.set_fused_enabled(fused)
+            for graph in (False, True):
+                mg = HierarchyMG(A, rhs.copy(), hier)
+                mg.solve(use_graph=graph, **kw)
+                assert all(ops.stencil_smooth_available(lev.A) == fused for lev in mg._hier.levels[:-1])
+                runs[fused, graph] = (mg.get_track_res(), mg.get_solution())
+    finally:
+        ops.set_fused_enabled(True)
+    t0, x0 = runs[False, False]
+    for key, (t, x) in runs.items():
+        assert np.array_equal(t, t0) and np.array_equal(x, x0), key
+    if steps == 3:
+        ref = oracle_run(A, rhs, hier, semantics="as_named", **{k: v for k, v in kw.items() if k != "smoother_semantics"})
+        assert_track(t0, ref.track_res)
+
+
 def test_default_smoother_graph_replay_2d():
     """solve(use_graph=True) with the DEFAULT semantics (forward Gauss-Seidel whatever the name says,
     Multigrid.py:88) on a 2-D grid whose level sets fit the one-workgroup executor: everything that

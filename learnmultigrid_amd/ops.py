@@ -540,13 +540,18 @@ def _stencil(mode, S, x, b, out, alpha, beta, partials, norm2):
 
 
 FUSED_MAX_SWEEPS = 3
+# Levels below this many rows run one launch per sweep: a fused pass walks its segment of lines
+# sequentially (>= 8 + 2 H dependent steps per wave), which costs more than the launches it saves once
+# the whole level is a few-microsecond kernel (measured: 1025^2 9-point, 3 sweeps + residual 63 us fused
+# vs ~30 us separate; 4097^2 5-point 198 us vs 310 us).
+FUSED_MIN_ROWS = 4_000_000
 
 
 def stencil_smooth_available(A):
     """True when `A` has a grid-stencil twin, i.e. stencil_smooth can run its smoothing passes fused."""
     S = getattr(A, "stencil", None)
     return bool(_PACKED_ENABLED and _STENCIL_ENABLED and _FUSED_ENABLED and S is not None
-                and _lib.lib().lmg_stencil_smooth_supported(S.umask))
+                and S.n >= FUSED_MIN_ROWS and _lib.lib().lmg_stencil_smooth_supported(S.umask))
 
 
 _FUSED_ENABLED = True

@@ -876,7 +876,7 @@ def test_fused_stencil_smoothing_equals_separate_sweeps(name, seg_lines, pf):
     n = A.shape[0]
     dA = ops.DeviceCSR.from_scipy(A, DEV)
     dA.pack()
-    assert ops.stencil_smooth_available(dA)
+    assert dA.stencil is not None and not ops.stencil_smooth_available(dA)        # small level: separate sweeps
     rng = np.random.default_rng(77)
     x0, b = rng.standard_normal(n), rng.standard_normal(n)
     try:

@@ -189,7 +189,9 @@ def test_fused_smoothing_passes_equal_separate_sweeps(m, levels, steps):
     kw = dict(levels=levels, smoother="Jacobi", smooth_steps=steps, max_iterations=6, error=1e-30,
               smoother_semantics="as_named", omega=0.8)
     runs = {}
+    min_rows = ops.FUSED_MIN_ROWS
     try:
+        ops.FUSED_MIN_ROWS = 0                       # (the product only fuses on multi-million-row levels)
         for fused in (False, True):
             ops.set_fused_enabled(fused)
             for graph in (False, True):
@@ -199,6 +201,7 @@ def test_fused_smoothing_passes_equal_separate_sweeps(m, levels, steps):
                 runs[fused, graph] = (mg.get_track_res(), mg.get_solution())
     finally:
         ops.set_fused_enabled(True)
+        ops.FUSED_MIN_ROWS = min_rows
     t0, x0 = runs[False, False]
     for key, (t, x) in runs.items():
         assert np.array_equal(t, t0) and np.array_equal(x, x0), key
@@ -327,6 +330,39 @@ def test_full_size_properties_4097():
     mg2.solve(levels=levels, smoother="Jacobi", smooth_steps=3, max_iterations=8, error=1e-30,
               smoother_semantics="as_named", omega=0.8, use_graph=True)
     assert np.array_equal(mg2.get_solution(), 2.0 * mg.get_solution())   # exact: scaling by 2
+    # the fine level runs its sweeps fused (lmg_stencil_smooth); one launch per sweep gives the same bits,
+    # and the fused pass itself matches the CPU oracle's separate sweeps at full size
+    from learnmultigrid_amd import ops
+    from oracle import kernels as K
+    assert ops.stencil_smooth_available(mg._hier.levels[0].A)
+    assert not ops.stencil_smooth_available(mg._hier.levels[2].A)
+    try:
+        ops.set_fused_enabled(False)
+        mg3 = HierarchyMG(A, rhs.copy(), hier)
+        mg3.solve(levels=levels, smoother="Jacobi", smooth_steps=3, max_iterations=8, error=1e-30,
+                  smoother_semantics="as_named", omega=0.8)
+    finally:
+        ops.set_fused_enabled(True)
+    assert np.array_equal(mg3.get_track_res(), mg.get_track_res())
+    assert np.array_equal(mg3.get_solution(), mg.get_solution())
+    n = A.shape[0]
+    rng = np.random.default_rng(5)
+    x0, b = rng.standard_normal(n), rng.standard_normal(n)
+    Ac = K.as_csr(A)
+    want = x0
+    for _ in range(3):
+        want = K.jacobi(Ac, want, b, 0.8)
+    wr, _ = K.residual(Ac, want, b)
+    dA = mg._hier.levels[0].A
+    dx, db = torch.from_numpy(x0).to("cuda:0"), torch.from_numpy(b).to("cuda:0")
+    out, r = torch.empty_like(dx), torch.empty_like(dx)
+    ops.stencil_smooth(dA, dx, db, 0.8, 3, out, r)
+    assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(r.cpu().numpy(), wr)
+    want0 = np.zeros(n)
+    for _ in range(2):
+        want0 = K.jacobi(Ac, want0, b, 0.8)
+    ops.stencil_smooth(dA, None, db, 0.8, 2, out, None)
+    assert np.array_equal(out.cpu().numpy(), want0)
 
 
 def test_g6_cg_matches_reference():

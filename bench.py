@@ -69,9 +69,53 @@ def parse():
                     help="learned = row-stochastic perturbed L2-type Q per level (cfg#3/#5)")
     ap.add_argument("--rebuild", type=int, default=0, help="time this many numeric Galerkin rebuilds (cfg#5)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-tts", action="store_true", help="skip the time-to-solution leg")
     ap.add_argument("--no-packed", action="store_true", help="plain CSR kernels (no lossless twins at all)")
     ap.add_argument("--no-patterns", action="store_true", help="packed CSR twin only (no row-pattern twin)")
     return ap.parse_args()
+
+
+def cpu_info():
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    pools = []
+    try:
+        from threadpoolctl import threadpool_info
+        pools = [{k: d.get(k) for k in ("user_api", "internal_api", "num_threads")} for d in threadpool_info()]
+    except Exception:
+        pass
+    return {"model": model, "logical_cpus": os.cpu_count() or 0, "threadpools": pools,
+            "note": "the oracle's C loops and SciPy's sparse kernels are single-threaded: 1 core does the work"}
+
+
+def solve_to_tolerance(H, rhs, nu, omega, abs_tol=1e-10, max_cycles=60):
+    """x = 0, then V(nu,nu) cycles (hipGraph replay) until ||b - A x||_2 <= abs_tol -- the scripts' stopping
+    test `error=1e-10` (test/test_B_patch.py:193, Multigrid.py:69): cycles, seconds, final relative residual."""
+    import torch
+    from learnmultigrid_amd import ops
+    fine = H.levels[0]
+    with torch.cuda.stream(H.stream):
+        fine.b.copy_(torch.from_numpy(rhs.ravel().copy()).to(H.device))
+        g = H.captured_cycle("Jacobi", nu, omega, "lexicographic")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ops.zero(fine.x)
+        r0 = H.residual_norm(want_vector=False)
+        r, cycles = r0, 0
+        while r > abs_tol and cycles < max_cycles:
+            g.launch()
+            cycles += 1
+            r = H.residual_norm(want_vector=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return cycles, dt, (r / r0 if r0 > 0 else 0.0)
 
 
 def cpu_baseline(A, hier, rhs, args):
@@ -105,7 +149,9 @@ def cpu_baseline(A, hier, rhs, args):
     out = {"value": n * sweeps / dt, "unit": "DoF*sweeps/s", "cores": 1, "kind": "port",
            "sample": "%s of the same %d-DoF problem in %.1f s (setup %.1f s not counted), "
                      "oracle/ single thread; host has %d logical CPUs"
-                     % (what, n, dt, t_setup, os.cpu_count() or 0)}
+                     % (what, n, dt, t_setup, os.cpu_count() or 0),
+           "cpu": cpu_info(), "setup_s": t_setup,
+           "s_per_cycle": dt / args.cpu_cycles if args.mode == "vcycle" else None}
     if args.mode == "vcycle":
         # for honesty: ONE cycle the way the reference really runs it -- forward
         # Gauss-Seidel whatever the smoother argument says, transfer lookup, R A P and the SuperLU
@@ -297,39 +343,74 @@ def main():
         copy_gbps = max(copy_gbps, 2 * cp_src.numel() * 8 / (ev0.elapsed_time(ev1) * 1e-3 / 10) / 1e9)
         del cp_src, cp_dst
     B = sweep_bytes(fine_A.shape[0], fine_A.nnz)
-    achieved = B / t_jac / 1e9
+    st_ = fine_A.stencil if (ops._PACKED_ENABLED and ops._STENCIL_ENABLED) else None
     rp_ = fine_A.patterns if ops._PACKED_ENABLED else None
     pk = fine_A.packed if (ops._PACKED_ENABLED and rp_ is None) else None
-    kind = "rpat" if rp_ is not None else ("pcsr" if pk is not None else "csr")
+    sl = fine_A.sell if (ops._PACKED_ENABLED and rp_ is None and pk is None) else None
+    kind = "stencil" if st_ is not None else ("rpat" if rp_ is not None else ("pcsr" if pk is not None else
+                                                                              ("sell" if sl is not None else "csr")))
     # bytes the launch really has to move: the lossless twin of the CSR arrays (DESIGN.md
     # section 3) + x once + b + output
-    twin = rp_ if rp_ is not None else pk
-    B_stored = (twin.bytes() if twin is not None else fine_A.bytes()) + 24 * fine_A.shape[0]
-    if rp_ is not None:
+    twin = st_ if st_ is not None else (rp_ if rp_ is not None else (pk if pk is not None else sl))
+    nrow = fine_A.shape[0]
+    B_moved = (twin.bytes() if twin is not None else fine_A.bytes()) + 24 * nrow
+    if st_ is not None:
+        kname = ("stencil_sweep_kernel<JACOBI> (grid stencil: %d patterns, line stride %d, 1 B/row of matrix)"
+                 % (st_.npat, st_.W))
+    elif rp_ is not None:
         kname = "rpat_sweep_kernel<JACOBI> (row patterns: %d distinct rows, %d entries, 1 B/row)" % (rp_.npat, rp_.nent)
     elif pk is not None:
         kname = ("pcsr_sweep_kernel<JACOBI> (packed CSR: colmode %d, valmode %d, %d dictionary values)"
                  % (pk.colmode, pk.valmode, pk.ndict))
+    elif sl is not None:
+        kname = "sell_sweep_kernel<JACOBI> (sliced ELL, colmode %d)" % sl.colmode
     else:
         kname = "csr_sweep_kernel<JACOBI>"
+    pmc = PMC_TRAFFIC.get((args.size, kind)) if (world == 1 and not force_dist and args.problem == "poisson") else None
+    achieved = B_moved / t_jac / 1e9
     roofline = {"bound": "hbm",
                 "kernel": kname,
+                "what": "ONE fine-level weighted-Jacobi sweep (the kernel the north-star target is quoted on), HIP events "
+                        "around %d launches on the launch stream; achieved = bytes the kernel has to move / avg launch" % reps,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": PMC_TRAFFIC.get((args.size, kind)) if (world == 1 and not force_dist
-                                                                  and args.problem == "poisson") else None,
-                "copy_ceiling_GBps": copy_gbps,
+                "moved_bytes_per_launch": B_moved,
+                "traffic": None if pmc is None else pmc[0],
+                "traffic_source": None if pmc is None else
+                "%s (separate rocprofv3 --pmc passes of this kernel, NOT this run: 2 x FETCH_SIZE + WRITE_SIZE)" % pmc[1],
+                "avg_launch_ms": t_jac * 1e3, "rows_per_launch": int(nrow),
+                "copy_ceiling_GBps": copy_gbps, "frac_of_copy_ceiling": achieved / copy_gbps,
+                # the same sweep priced in the CSR bytes of SURVEY.md 8(d): what a CSR stream would have to
+                # sustain to be as fast -- a rate of WORK, not of bytes moved, hence not a roofline fraction
+                "csr_equivalent_bytes_per_launch": B, "csr_equivalent_GBps": B / t_jac / 1e9,
+                "byte_reduction_vs_csr": B / B_moved,
                 "csr_kernel_same_sweep": None if t_csr is None else {
                     "kernel": "csr_sweep_kernel<JACOBI>", "avg_launch_ms": t_csr * 1e3, "GBps": B / t_csr / 1e9,
-                    "frac_of_peak": B / t_csr / 1e9 / HBM_PEAK_GBS, "frac_of_copy_ceiling": B / t_csr / 1e9 / copy_gbps},
-                "algorithmic_bytes_per_launch": B, "avg_launch_ms": t_jac * 1e3,
-                "rows_per_launch": int(fine_A.shape[0]),
-                "stored_bytes_per_launch": B_stored,
-                "stored_GBps": B_stored / t_jac / 1e9, "stored_frac_of_peak": B_stored / t_jac / 1e9 / HBM_PEAK_GBS,
-                "stored_frac_of_copy_ceiling": B_stored / t_jac / 1e9 / copy_gbps,
-                "note": "achieved = ALGORITHMIC CSR bytes (12 nnz + 4(n+1) + 24 n) / launch time; the kernel "
-                        "reads a lossless packed encoding, so HBM traffic (`traffic`, `stored_*`) is lower than "
-                        "the algorithmic bytes and `frac` can exceed what a CSR stream could reach"}
+                    "frac_of_peak": B / t_csr / 1e9 / HBM_PEAK_GBS, "frac_of_copy_ceiling": B / t_csr / 1e9 / copy_gbps}}
+    # the fused smoothing passes the cycle really launches on this level (3 sweeps [+ residual] per pass)
+    if world == 1 and not force_dist and args.mode == "vcycle" and ops.stencil_smooth_available(fine_A):
+        with torch.cuda.stream(stream):
+            ra = torch.empty_like(ya)
+            fused = {}
+            for lab, k_, r_ in (("pre_smoothing_%d_sweeps_plus_residual" % min(nu, 3), min(nu, 3), ra),
+                                ("post_smoothing_%d_sweeps" % min(nu, 3), min(nu, 3), None)):
+                for _ in range(2):
+                    ops.stencil_smooth(fine_A, xa, ba, args.omega, k_, ya, r_)
+                ev0.record(stream)
+                for _ in range(20):
+                    ops.stencil_smooth(fine_A, xa, ba, args.omega, k_, ya, r_)
+                ev1.record(stream)
+                torch.cuda.synchronize()
+                tf = ev0.elapsed_time(ev1) * 1e-3 / 20
+                moved = nrow * (1 + 24 + (8 if r_ is not None else 0))
+                napply = k_ + (1 if r_ is not None else 0)
+                fused[lab] = {"kernel": "stencil_fused_kernel", "avg_launch_ms": tf * 1e3,
+                              "operator_applications_per_launch": napply,
+                              "compulsory_bytes_per_launch": moved, "GBps": moved / tf / 1e9,
+                              "frac": moved / tf / 1e9 / HBM_PEAK_GBS,
+                              "ms_per_operator_application": tf * 1e3 / napply,
+                              "separate_launches_would_take_ms": napply * t_jac * 1e3}
+            roofline["fused_passes_in_the_cycle"] = fused
     cyc_bytes, coarse_bytes = H.cycle_bytes(nu) if args.mode == "vcycle" and world == 1 else (None, None)
     if world > 1 or force_dist:
         out_extra = {"distributed_levels": D.n_dist, "rows_per_rank_fine": n_loc_fine,
@@ -360,10 +441,14 @@ def main():
            "unit": "DoF*sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "2-D structured P1 Poisson %dx%d elements (%d DoF, %d nnz, CSR "
-                                  "fp64/int32), %d-level V(%d,%d) cycle, weighted Jacobi omega=%.2f, "
-                                  "tensor-product geometric transfer, Galerkin RAP by device SpGEMM"
-                                  % (m, m, n, nnz, levels, nu, nu, args.omega),
+           "config": {"workload": "%s %dx%d elements (%d DoF, %d nnz, CSR fp64/int32), %d-level V(%d,%d) cycle, "
+                                  "weighted Jacobi omega=%.2f, %s, Galerkin RAP by device SpGEMM"
+                                  % ({"poisson": "2-D structured P1 Poisson",
+                                      "varcoeff": "2-D variable-coefficient P1 stiffness (k = exp(0.5 N(0,1)) smoothed, seed 44)",
+                                      "jittered": "2-D P1 Poisson on a jittered triangulation (7-point, seed 42)"}[args.problem],
+                                     m, m, n, nnz, levels, nu, nu, args.omega,
+                                     {"geometric": "tensor-product geometric transfer",
+                                      "learned": "learned-like transfer (row-stochastic perturbed L2-type Q, seeds 43+level)"}[args.transfer]),
                       "mode": args.mode, "step": "one full V-cycle" if args.mode == "vcycle"
                       else "1 Jacobi sweep + 1 residual on the fine level",
                       "fine_sweeps_per_step": sweeps_per_step,
@@ -387,6 +472,29 @@ def main():
         out["coarse_dense_bytes"] = coarse_bytes
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(A, hier, rhs, args)
+    if rank == 0 and world == 1 and not force_dist and args.mode == "vcycle" and not args.no_tts:
+        # time to solution (||r||_2 <= 1e-10 from x = 0, the scripts' `error=1e-10`): upload + setup + cycles, next to the CPU oracle's
+        # setup + the same number of its timed cycles (same arithmetic, hence the same cycle count)
+        cyc, t_solve, rel = solve_to_tolerance(H, rhs, nu, args.omega)
+        tts = {"this_config": {"cycles": cyc, "final_relative_residual": rel,
+                               "setup_s_cold_incl_upload": setup_s, "solve_s": t_solve,
+                               "time_to_solution_s": setup_s + t_solve}}
+        cb = out.get("cpu_baseline")
+        if cb and cb.get("s_per_cycle"):
+            tts["this_config"]["cpu_time_to_solution_s"] = cb["setup_s"] + cyc * cb["s_per_cycle"]
+            tts["this_config"]["cpu_note"] = "oracle setup + %d x its measured cycle time (1 core)" % cyc
+        if args.problem == "poisson" and args.transfer == "geometric" and args.size != 512:
+            m2 = 512                                                             # cfg#2: 513^2, 3 levels
+            A2, rhs2 = P.poisson_2d_structured(m2)
+            t0 = time.perf_counter()
+            H2 = Hierarchy(A2, P.geometric_hierarchy_2d(m2 + 1, 3), dev)
+            torch.cuda.synchronize()
+            s2 = time.perf_counter() - t0
+            c2, ts2, rel2 = solve_to_tolerance(H2, rhs2, nu, args.omega)
+            tts["cfg2_513x513_3_levels"] = {"cycles": c2, "final_relative_residual": rel2, "setup_s_warm_incl_upload": s2,
+                                            "solve_s": ts2, "time_to_solution_s": s2 + ts2}
+            del H2
+        out["time_to_solution"] = tts
     if rank == 0:
         print(json.dumps(out))
     if dist.is_initialized():

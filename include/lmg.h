@@ -263,6 +263,24 @@ int lmg_csr_gs_schedule_ell(int64_t n, const double *d_vals, double *d_x, const 
                             int32_t ell_k, int64_t total_rows, const int32_t *d_set_ptr, int64_t nsets,
                             int sweeps, void *stream);
 
+/* Exact forward (lexicographic) Gauss-Seidel on a grid-stencil matrix (format arguments of
+ * lmg_stencil_sweep) as a pipelined wavefront in registers: a wave owns 64 grid lines, lane l relaxes
+ * column t - SK*l of its line at step t, neighbouring bands hand their boundary line over through memory
+ * behind a progress counter (csrc/gs_wave.hip).  `sweeps` forward sweeps in place on d_x: the same bits as
+ * lmg_csr_gs_schedule on the level schedule and as pyamg's gauss_seidel (Multigrid.py:88, :121), at ~0.15 us
+ * per dependent anti-diagonal instead of a kernel launch each.  Requirements (the caller checks them:
+ * ops.StencilTwin.gs_ok): union_mask accepted by lmg_stencil_gs_supported (5-, 7-, 9-point, 1-D), and no
+ * pattern used in column 0 / line_stride-1 of a line couples across the line end.  hot_pattern /
+ * h_hot_val as in lmg_stencil_smooth (steps in which every lane relaxes that pattern skip the LDS table).  d_work:
+ * lmg_stencil_gs_work_bytes(n, line_stride) bytes, 8-byte aligned, its last int32 zeroed by the caller
+ * once (it is set when a band had to give up waiting: the result is then invalid). */
+int lmg_stencil_gs_supported(uint32_t union_mask);
+int64_t lmg_stencil_gs_work_bytes(int64_t n, int32_t line_stride);
+int lmg_stencil_gs_sweep(int64_t n, int32_t line_stride, const uint8_t *d_pid, int32_t npat,
+                         const double *d_st_val, const int32_t *d_st_mask, uint32_t union_mask,
+                         int32_t hot_pattern, const double *h_hot_val, double *d_x, const double *d_b,
+                         void *d_work, int sweeps, void *stream);
+
 /* HOST helpers (host pointers, run on the CPU at setup time).
  * level[i] = 1 + max(level[j] : j < i adjacent to i in A + A^T), 0 if none: rows of equal
  * level are independent, executing levels in order IS the lexicographic sweep.

@@ -59,6 +59,9 @@ SIGNATURES = {
     "lmg_csr_gs_rows": (_c.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p]),
     "lmg_csr_gs_schedule": (_c.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _c.c_int, _p]),
     "lmg_csr_gs_schedule_ell": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _p, _i64, _c.c_int, _p]),
+    "lmg_stencil_gs_supported": (_c.c_int, [_c.c_uint32]),
+    "lmg_stencil_gs_work_bytes": (_i64, [_i64, _i32]),
+    "lmg_stencil_gs_sweep": (_c.c_int, [_i64, _i32, _p, _i32, _p, _p, _c.c_uint32, _i32, _p, _p, _p, _p, _c.c_int, _p]),
     "lmg_host_gs_levels": (_i64, [_i64, _p, _p, _p]),
     "lmg_host_greedy_colors": (_i64, [_i64, _p, _p, _p]),
     "lmg_axpby": (_c.c_int, [_i64, _f64, _p, _f64, _p, _p]),

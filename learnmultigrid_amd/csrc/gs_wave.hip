@@ -1,0 +1,346 @@
+// Exact forward (lexicographic) Gauss-Seidel on grid-stencil matrices for gfx950: a pipelined wavefront
+// in registers instead of one dependent kernel launch (or workgroup barrier) per anti-diagonal.
+//
+// pyamg's gauss_seidel (Multigrid.py:88, :121) relaxes row i with the NEW values of all columns j < i and the
+// OLD values of all j > i.  On a grid-stencil matrix (format of stencil.hip: every entry at column - row =
+// c*W + d, c, d in {-1, 0, 1}) with no coupling across line ends, row (y, x) needs the new values of
+// (y-1, x-1 .. x+1) and (y, x-1): a chain of W + (#lines) * SK dependent updates, SK = 2 when the upper-right
+// neighbour (y-1, x+1) is coupled, else 1.  That chain is the critical path of ANY exact implementation;
+// what can be removed is everything else on it.  csr_gs_schedule pays a launch (5.3 us) or a workgroup
+// barrier plus an L2 round trip (2.4 us) per anti-diagonal.  Here:
+//   * a WAVE owns a band of 64 consecutive lines, lane l the line y0 + l, and at step t lane l relaxes
+//     column t - SK*l: the new value a lane needs from the line above was produced by lane l-1 one step
+//     earlier and arrives through a DPP wave shift; its own previous result is in a register; the old values
+//     of its own line and of the line below, b and the pattern id are loaded PF steps ahead.  One step is
+//     the arithmetic of one row (a handful of multiply-adds and one IEEE division), ~0.15 us.
+//   * bands are pipelined against each other through memory: the last lane of a band stores its results
+//     write-through (sc1) and publishes "columns done" a few steps later behind a COUNTED s_waitcnt (the
+//     stores of that many steps ago have completed; nothing stalls), lane 0 of the next band prefetches that
+//     counter and the values above its line with sc1 loads and only spins when it has caught up.  A band
+//     therefore trails its predecessor by 64*SK steps plus two memory latencies.
+//   * bands are handed out by an atomic ticket, so a band only ever waits for one that is already running
+//     (no assumption about the dispatch order of workgroups).
+// Same row arithmetic in the same order as gs_update_row (rsum over the off-diagonal entries in column order,
+// (b - rsum) / diag, rows with a zero diagonal untouched): bit-identical to the level-scheduled sweep and to
+// the CPU oracle.  4097^2: one sweep ~1.5 ms instead of 43.7 ms (8191 launches); 513^2 ~0.25 ms instead of 2.5.
+#include <string.h>
+#include "lmg_common.hpp"
+
+namespace {
+
+constexpr int kMaxPat = 64;
+constexpr int kPF = 6;                      // iterations (of two steps) between issuing a load and using its value
+constexpr int kPubDelay = 7;                // iterations between a result store and the progress that covers it: the
+                                            // counted wait in front of the progress store also covers every LOAD issued
+                                            // before that store, so it must not be shorter than the prefetch distance
+constexpr int kVmOpsPerIter = 9;            // vector-memory instructions per iteration: 6 loads, 2 result stores, progress
+constexpr unsigned kMask5 = 0x0BAu, kMask9 = 0x1FFu, kMask7 = 0x1BBu, kMask1D = 0x038u;
+constexpr unsigned kOOB = 0xFFFFFFF0u;      // buffer offset beyond any num_records: the access is dropped / reads 0
+constexpr int kSc1 = 16;                    // buffer cache policy: sc1 (write-through / L1 bypass, agent scope)
+
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+
+struct GArgs {
+    int n, W, lines, nbands, npat;
+    const unsigned char *pid;
+    const double *st_val;
+    const int *st_mask;
+    double *x;
+    const double *b;
+    int hot;                                // interior pattern (all union slots, non-zero diagonal) or -1
+    double hot_val[9];
+    int *work;                              // [0] ticket, [1 + k] columns done on the last line of band k,
+                                            // [1 + nbands] where the other lanes "publish", [2 + nbands] error flag
+};
+
+__device__ __forceinline__ double dpp_lower(double src)      // lane i <- lane i-1, lane 0 <- 0
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lo2(const u4 &v) { return __hiloint2double((int)v.y, (int)v.x); }
+__device__ __forceinline__ double hi2(const u4 &v) { return __hiloint2double((int)v.w, (int)v.z); }
+
+// elements i, i+1 of a double array through a buffer resource: out-of-range pairs read 0; the two pairs that
+// straddle the first / last element are read one element further in and sorted out by the consumer
+// (`straddle`: +1 = i == n-1, -1 = i == -1), so that no access is ever PARTLY out of range
+__device__ __forceinline__ unsigned pair_off(int64_t i, int n)
+{
+    const int64_t j = i + (i == -1 ? 1 : 0) - (i == (int64_t)n - 1 ? 1 : 0);
+    return (j >= 0 && j + 1 < n) ? (unsigned)j * 8u : kOOB;
+}
+
+struct Ahead {          // what iteration it + kPF needs (two columns), on its way through memory
+    u4 own, down, up, b;
+    int pid2, flag;
+};
+
+template <unsigned UM>
+__global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
+{
+    constexpr int SK = (UM & 4u) ? 2 : 1;
+    __shared__ double s_val[kMaxPat * 9];
+    __shared__ int s_mask[kMaxPat];
+    __shared__ int s_band;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < a.npat * 9; i += 64) s_val[i] = a.st_val[i];
+    for (int i = lane; i < a.npat; i += 64) s_mask[i] = a.st_mask[i];
+    if (lane == 0) s_band = atomicAdd(&a.work[0], 1);
+    __syncthreads();
+    const int band = __builtin_amdgcn_readfirstlane(s_band);
+    if (band >= a.nbands) return;
+
+    const int n = a.n, W = a.W;
+    const int y = band * 64 + lane;
+    const bool line_ok = y < a.lines;
+    const int64_t base = (int64_t)y * W;
+    const int last_lane = min(63, a.lines - 1 - band * 64);          // lane of the band's last line
+    int *prog_mine = a.work + 1 + (lane == last_lane ? band : a.nbands);      // other lanes: a dummy word
+    const int *prog_prev = a.work + (band > 0 ? band : 0);            // band 0 reads the ticket word and ignores it
+    const int ITER = (W + SK * 63 + 1) / 2 + 1;                       // iterations of a band (two steps each)
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a.x, 0, (int)((unsigned)n * 8u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)a.b, 0, (int)((unsigned)n * 8u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void *)a.pid, 0, n, 0x00020000);
+
+    // loads of iteration itf (columns xf, xf + 1 with xf = 2 itf - SK lane): always the same six instructions
+    auto fetch = [&](int itf, Ahead &A) {
+        const int xf = 2 * itf - SK * lane;
+        const int64_t i = base + xf;
+        A.own = __builtin_amdgcn_raw_buffer_load_b128(rs_x, pair_off(i + 1, n), 0, 0);          // old (y, xf+1), (y, xf+2)
+        A.down = __builtin_amdgcn_raw_buffer_load_b128(rs_x, pair_off(i + W + 1, n), 0, 0);     // old (y+1, xf+1), (y+1, xf+2)
+        A.b = __builtin_amdgcn_raw_buffer_load_b128(rs_b, pair_off(i, n), 0, 0);
+        {
+            const int64_t j = i + (i == -1 ? 1 : 0) - (i == (int64_t)n - 1 ? 1 : 0);
+            A.pid2 = (int)__builtin_amdgcn_raw_buffer_load_b16(rs_p, (j >= 0 && j + 1 < n) ? (unsigned)j : kOOB, 0, 0);
+        }
+        // lane 0: new (y-1, xf+SK-1), (y-1, xf+SK) of the previous band, write-through data -> L1 bypass
+        A.up = __builtin_amdgcn_raw_buffer_load_b128(rs_x, lane == 0 ? pair_off(i - W + (SK - 1), n) : kOOB, 0, kSc1);
+        A.flag = __hip_atomic_load(prog_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // lane 0's read of the line above is only legal once the previous band has published those columns
+    int spin_budget = 1 << 22;
+    auto wait_for_prev = [&](int itf, int flag_seen) {
+        if (band == 0) return;
+        int need = min(W, 2 * itf + SK + 1);                          // columns 0 .. 2 itf + SK done
+        int f = __builtin_amdgcn_readfirstlane(flag_seen);
+        if (f >= need) return;
+        // Caught up with the previous band: wait until it is comfortably ahead (or done), not just one column --
+        // a band that trails by exactly the dependency distance would come back here every iteration and advance
+        // at one memory round trip per iteration (measured: 1.5 us instead of 0.3)
+        need = min(W, need + 8 * kPF);
+        // (bounded: the previous band holds an earlier ticket, so it is running or done and its counter only
+        // grows; the budget -- a few seconds per band in total -- turns a protocol bug into a wrong result with
+        // an error flag instead of a hung GPU)
+        while (f < need && spin_budget > 0) {
+            --spin_budget;
+            __builtin_amdgcn_s_sleep(2);
+            f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(prog_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        if (f < need && lane == 0) a.work[2 + a.nbands] = 1;
+    };
+
+    double U0 = 0.0, U1 = 0.0, U2 = 0.0;      // new values of the line above at columns x-1, x, x+1
+    double D0 = 0.0, D1 = 0.0, D2 = 0.0;      // old values of the line below
+    double O0 = 0.0, O1 = 0.0;                // old values of the own line at columns x, x+1
+    double R = 0.0;                           // own result of the previous step = new (y, x-1)
+    Ahead ring[kPF];
+    int flag_seen = 0;
+    // prologue: the first kPF iterations' loads (lane 0's line-above loads need the previous band first)
+#pragma unroll
+    for (int u = 0; u < kPF; ++u) {
+        wait_for_prev(u, flag_seen);
+        fetch(u, ring[u]);
+    }
+    {   // windows just before the first step (column x0 = -SK lane): what the first shift moves into place
+        const int64_t i0 = base - SK * lane;
+        auto one = [&](int64_t i) {
+            const u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs_x, (i >= 0 && i < n) ? (unsigned)i * 8u : kOOB, 0, kSc1);
+            return __hiloint2double((int)v.y, (int)v.x);
+        };
+        O1 = one(i0);                         // old (y, x0)
+        D2 = one(i0 + W);                     // old (y+1, x0)
+        D1 = one(i0 + W - 1);                 // old (y+1, x0-1)
+        if (SK == 2 && lane == 0 && band > 0) U2 = one(i0 - W);             // new (y-1, 0): becomes U1 at column 0
+    }
+
+    // hot pattern (the interior row): values in scalar registers, used when every lane of the wave relaxes
+    // such a row in this step -- no LDS reads, no selects, the same products and sums in the same order
+    const int hot = a.hot;
+    double hv[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) hv[q] = a.hot_val[q];
+
+    // one step = one column: windows move one to the right, then row (y, x) is relaxed
+    auto step = [&](int x, double up_top, double down_new, double own_new, double bval, int p_in) -> double {
+        U0 = U1;
+        U1 = U2;
+        if (SK == 2) U2 = up_top;
+        else U1 = up_top;
+        D0 = D1;
+        D1 = D2;
+        D2 = down_new;
+        O0 = O1;
+        O1 = own_new;
+        const int64_t i = base + x;
+        const bool act = line_ok && x >= 0 && x < W && i < n;
+        double xn;
+        if (__all(act && p_in == hot)) {                       // wave-uniform
+            double rsum = 0.0;
+            if ((UM >> 0) & 1u) rsum = rsum + hv[0] * U0;
+            if ((UM >> 1) & 1u) rsum = rsum + hv[1] * U1;
+            if ((UM >> 2) & 1u) rsum = rsum + hv[2] * U2;
+            if ((UM >> 3) & 1u) rsum = rsum + hv[3] * R;
+            if ((UM >> 5) & 1u) rsum = rsum + hv[5] * O1;
+            if ((UM >> 6) & 1u) rsum = rsum + hv[6] * D0;
+            if ((UM >> 7) & 1u) rsum = rsum + hv[7] * D1;
+            if ((UM >> 8) & 1u) rsum = rsum + hv[8] * D2;
+            xn = (bval - rsum) / hv[4];
+            R = xn;
+        } else {
+            const int p = act ? p_in : 0;
+            const int m = act ? s_mask[p] : 0;
+            double vv[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) vv[q] = ((UM >> q) & 1u) ? s_val[p * 9 + q] : 0.0;     // all reads up front
+            double rsum = 0.0;
+            double t_;
+            if ((UM >> 0) & 1u) { t_ = rsum + vv[0] * U0; rsum = ((m >> 0) & 1) ? t_ : rsum; }
+            if ((UM >> 1) & 1u) { t_ = rsum + vv[1] * U1; rsum = ((m >> 1) & 1) ? t_ : rsum; }
+            if ((UM >> 2) & 1u) { t_ = rsum + vv[2] * U2; rsum = ((m >> 2) & 1) ? t_ : rsum; }
+            if ((UM >> 3) & 1u) { t_ = rsum + vv[3] * R; rsum = ((m >> 3) & 1) ? t_ : rsum; }
+            if ((UM >> 5) & 1u) { t_ = rsum + vv[5] * O1; rsum = ((m >> 5) & 1) ? t_ : rsum; }
+            if ((UM >> 6) & 1u) { t_ = rsum + vv[6] * D0; rsum = ((m >> 6) & 1) ? t_ : rsum; }
+            if ((UM >> 7) & 1u) { t_ = rsum + vv[7] * D1; rsum = ((m >> 7) & 1) ? t_ : rsum; }
+            if ((UM >> 8) & 1u) { t_ = rsum + vv[8] * D2; rsum = ((m >> 8) & 1) ? t_ : rsum; }
+            const double diag = ((m >> 4) & 1) ? vv[4] : 0.0;
+            const double q_ = (bval - rsum) / (diag != 0.0 ? diag : 1.0);
+            xn = diag != 0.0 ? q_ : O0;
+            R = act ? xn : R;
+        }
+        return xn;
+    };
+
+    for (int ib = 0; ib < ITER; ib += kPF) {
+#pragma unroll
+        for (int u = 0; u < kPF; ++u) {
+            const int it = ib + u;
+            const int x = 2 * it - SK * lane;             // columns x, x + 1 in this iteration
+            const Ahead cur = ring[u];
+            flag_seen = cur.flag;
+            const int64_t i = base + x;
+            // which half of a pair is which (only the pairs straddling element 0 / n-1 are special)
+            auto first = [&](const u4 &v, int64_t ii) { return ii == (int64_t)n - 1 ? hi2(v) : lo2(v); };
+            auto second = [&](const u4 &v, int64_t ii) { return ii == -1 ? lo2(v) : hi2(v); };
+            const int pa = (i == (int64_t)n - 1) ? (cur.pid2 >> 8) & 0xff : cur.pid2 & 0xff;
+            const int pb = (i == -1) ? cur.pid2 & 0xff : (cur.pid2 >> 8) & 0xff;
+            // ---- next loads ----------------------------------------------------------------------------
+            wait_for_prev(it + kPF, flag_seen);
+            fetch(it + kPF, ring[u]);
+            // ---- two steps -----------------------------------------------------------------------------
+            // (the wave shifts run with all lanes enabled: a DPP read from a lane that a branch has switched off
+            // returns the destination's old value, not the neighbour's)
+            const double inA = dpp_lower(R);
+            const double upA = lane == 0 ? first(cur.up, i - W + (SK - 1)) : inA;
+            const double xa = step(x, upA, first(cur.down, i + W + 1), first(cur.own, i + 1), first(cur.b, i), pa);
+            const double inB = dpp_lower(R);
+            const double upB = lane == 0 ? second(cur.up, i - W + (SK - 1)) : inB;
+            const double xb = step(x + 1, upB, second(cur.down, i + W + 1), second(cur.own, i + 1), second(cur.b, i), pb);
+            // ---- results: one 16-byte and one 8-byte write-through store, disabled ones out of range ----------
+            const bool actA = line_ok && x >= 0 && x < W && i < n, actB = line_ok && x + 1 >= 0 && x + 1 < W && i + 1 < n;
+            u4 v4;
+            v4.x = (unsigned)__double2loint(xa);
+            v4.y = (unsigned)__double2hiint(xa);
+            v4.z = (unsigned)__double2loint(xb);
+            v4.w = (unsigned)__double2hiint(xb);
+            __builtin_amdgcn_raw_buffer_store_b128(v4, rs_x, (actA && actB) ? (unsigned)i * 8u : kOOB, 0, kSc1);
+            u2 v2;
+            v2.x = actA ? v4.x : v4.z;
+            v2.y = actA ? v4.y : v4.w;
+            __builtin_amdgcn_raw_buffer_store_b64(v2, rs_x, (actA != actB) ? (unsigned)(actA ? i : i + 1) * 8u : kOOB, 0, kSc1);
+            // ---- publish: the result stores of kPubDelay iterations ago have completed ----------------------
+            {
+                constexpr int N = kVmOpsPerIter * (kPubDelay - 1);
+                static_assert(N < 64 && kVmOpsPerIter * kPF < 64, "vmcnt range");
+                __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
+                // last line: after iteration it' its columns 0 .. 2 it' + 1 - SK last_lane are done
+                const int done = min(W, 2 * (it - kPubDelay) + 2 - SK * last_lane);
+                __hip_atomic_store(prog_mine, max(done, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // everything of this band is done once all stores have completed
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+    __hip_atomic_store(prog_mine, W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <unsigned UM>
+int launch(GArgs a, hipStream_t st)
+{
+    hipLaunchKernelGGL((gs_wavefront_kernel<UM>), dim3((unsigned)a.nbands), dim3(64), 0, st, a);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lmg_stencil_gs_supported(uint32_t union_mask)
+{
+    return union_mask == kMask5 || union_mask == kMask9 || union_mask == kMask7 || union_mask == kMask1D;
+}
+
+int64_t lmg_stencil_gs_work_bytes(int64_t n, int32_t line_stride)
+{
+    if (n <= 0 || line_stride <= 0) return 0;
+    const int64_t lines = (n + line_stride - 1) / line_stride, nbands = (lines + 63) / 64;
+    return 4 * (nbands + 3) + 4;
+}
+
+int lmg_stencil_gs_sweep(int64_t n, int32_t line_stride, const uint8_t *pid, int32_t npat, const double *st_val,
+                         const int32_t *st_mask, uint32_t union_mask, int32_t hot_pattern, const double *h_hot_val,
+                         double *x, const double *b, void *work, int sweeps, void *stream)
+{
+    if (n < 0 || n >= (1ll << 29) - 8192 || npat < 1 || npat > kMaxPat || sweeps < 0) return LMG_ERR_ARG;        // 32-bit byte offsets
+    if (n == 0 || sweeps == 0) return LMG_OK;
+    if (n < 2) return LMG_ERR_CAPACITY;
+    if (!pid || !st_val || !st_mask || !x || !b || !work || line_stride < 3 || line_stride > n) return LMG_ERR_ARG;
+    if (!lmg_stencil_gs_supported(union_mask)) return LMG_ERR_CAPACITY;
+    GArgs a;
+    a.n = (int)n;
+    a.W = line_stride;
+    a.lines = (int)((n + line_stride - 1) / line_stride);
+    a.nbands = (a.lines + 63) / 64;
+    a.npat = npat;
+    a.pid = pid;
+    a.st_val = st_val;
+    a.st_mask = st_mask;
+    a.x = x;
+    a.b = b;
+    a.work = reinterpret_cast<int *>(work);
+    a.hot = -1;
+    for (int k = 0; k < 9; ++k) a.hot_val[k] = 0.0;
+    if (hot_pattern >= 0 && hot_pattern < npat && h_hot_val && h_hot_val[4] != 0.0) {
+        a.hot = hot_pattern;
+        for (int k = 0; k < 9; ++k) a.hot_val[k] = h_hot_val[k];
+    }
+    hipStream_t st = lmg_stream(stream);
+    for (int sw = 0; sw < sweeps; ++sw) {
+        // ticket and progress counters back to zero (a memset node when captured into a hipGraph)
+        // (the error flag at [2 + nbands] is cleared by the caller once and stays set)
+        if (hipMemsetAsync(a.work, 0, 4 * (size_t)(a.nbands + 2), st) != hipSuccess) return LMG_ERR_LAUNCH;
+        int rc;
+        switch (union_mask) {
+        case kMask5: rc = launch<kMask5>(a, st); break;
+        case kMask9: rc = launch<kMask9>(a, st); break;
+        case kMask7: rc = launch<kMask7>(a, st); break;
+        default: rc = launch<kMask1D>(a, st); break;
+        }
+        if (rc != LMG_OK) return rc;
+    }
+    return LMG_OK;
+}
+
+}  // extern "C"

@@ -175,7 +175,11 @@ class Hierarchy:
         if smoother == "GaussSeidel":
             if x_is_zero:
                 self.ops.zero(lev.x)
-            self.ops.csr_gs_schedule(lev.A, lev.x, lev.b, self.gs_schedule(l, gs_mode), steps)
+            if self._wavefront_gs(l, gs_mode):
+                # grid-stencil level: exact forward sweep as a pipelined wavefront, no schedule needed
+                self.ops.stencil_gs(lev.A, lev.x, lev.b, steps)
+            else:
+                self.ops.csr_gs_schedule(lev.A, lev.x, lev.b, self.gs_schedule(l, gs_mode), steps)
         elif smoother == "Jacobi":
             if x_is_zero:
                 if lev.dinv is None:
@@ -188,6 +192,10 @@ class Hierarchy:
                 lev.x, lev.tmp = lev.tmp, lev.x
         else:
             raise ValueError("unknown smoother %r" % (smoother,))
+
+    def _wavefront_gs(self, l, gs_mode):
+        avail = getattr(self.ops, "stencil_gs_available", None)
+        return gs_mode == "lexicographic" and avail is not None and avail(self.levels[l].A)
 
     def _fusable(self, l, smoother, steps):
         avail = getattr(self.ops, "stencil_smooth_available", None)
@@ -257,7 +265,11 @@ class Hierarchy:
         if g is None:
             if smoother == "GaussSeidel":
                 for l in range(len(self.levels) - 1):
-                    self.gs_schedule(l, gs_mode)            # host work must not happen in capture
+                    if self._wavefront_gs(l, gs_mode):
+                        # allocate the kernel's work buffer now: nothing may be allocated during capture
+                        self.ops.stencil_gs(self.levels[l].A, self.levels[l].tmp, self.levels[l].b, 0)
+                    else:
+                        self.gs_schedule(l, gs_mode)            # host work must not happen in capture
             before = [(lev.x, lev.tmp) for lev in self.levels]
             g = self.ops.CapturedGraph()
             with g:

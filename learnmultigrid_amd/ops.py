@@ -445,7 +445,8 @@ class StencilTwin:
     -- a few hundred numbers --; the per-row pattern ids are shared with the RowPatterns twin.
     from_patterns returns None for everything that does not fit (the RPAT kernel then runs)."""
 
-    __slots__ = ("n", "W", "npat", "pid", "st_val", "st_mask", "umask", "bytes_", "patterns", "hot", "_hot_val")
+    __slots__ = ("n", "W", "npat", "pid", "st_val", "st_mask", "umask", "bytes_", "patterns", "hot", "_hot_val",
+                 "gs_ok", "_gs_work")
 
     @staticmethod
     def _decompose(off, W):
@@ -473,17 +474,18 @@ class StencilTwin:
                 return None
         mx = int(np.abs(off).max()) if off.size else 0
         if mx <= 1:
-            cands = [max(3, int(R.n) - 1)]                        # 1-D: only the centre line is used
-            if R.n - 1 < 3:
+            cands = [int(R.n)]                                    # 1-D: one line, only the centre slots are used
+            if R.n < 3:
                 return None
         else:
             cands = [w for w in (mx, mx - 1, mx + 1) if 3 <= w < R.n]
-        for W in cands:
-            slots = [cls._decompose(int(o), W) for o in off]
-            if all(sl is not None for sl in slots):
-                break
-        else:
+        # several strides can fit (a 7-point operator {-W-1, -W, -1, 0, 1, W, W+1} also reads as a sheared
+        # stencil of stride W + 1): prefer the one that cuts the rows into whole lines
+        fits = [w for w in cands if all(cls._decompose(int(o), w) is not None for o in off)]
+        if not fits:
             return None
+        W = next((w for w in fits if R.n % w == 0), fits[0])
+        slots = [cls._decompose(int(o), W) for o in off]
         st_val = np.zeros(R.npat * 9)
         st_mask = np.zeros(R.npat, dtype=np.int32)
         for p in range(R.npat):
@@ -509,6 +511,15 @@ class StencilTwin:
             counts = torch.bincount(R.pid.long(), minlength=R.npat).cpu().numpy() if len(cand) > 1 else None
             self.hot = int(cand[0] if counts is None else max(cand, key=lambda p: counts[p]))
             self._hot_val = (ctypes.c_double * 9)(*[float(v) for v in st_val[self.hot * 9: self.hot * 9 + 9]])
+        # wavefront Gauss-Seidel (lmg_stencil_gs_sweep) needs a supported slot set and no coupling across the
+        # ends of a line: rows in column 0 must not reach column - 1, rows in column W - 1 not column + 1
+        self._gs_work = None
+        self.gs_ok = bool(_lib.lib().lmg_stencil_gs_supported(self.umask)) and self.n >= 2
+        if self.gs_ok:
+            mk = self.st_mask
+            first = mk[R.pid[0::W].long()]
+            last = mk[R.pid[W - 1::W].long()]
+            self.gs_ok = not bool(((first & 0x49) != 0).any()) and not bool(((last & 0x124) != 0).any())
         return self
 
     def bytes(self):
@@ -776,6 +787,48 @@ def _gs_ell(A, sched):
         cols[j] = torch.where(ln > j, A.colidx[idx], sched.d_rows)
     sched.ell = (key, K, sched.d_rows, start.contiguous(), ln.contiguous(), cols.contiguous(), total)
     return sched.ell
+
+
+_WAVE_GS_ENABLED = True
+
+
+def set_wavefront_gs_enabled(flag):
+    """Whether exact forward Gauss-Seidel on grid-stencil matrices runs the pipelined wavefront kernel
+    (default) or the level-scheduled executors (A/B runs and parity tests)."""
+    global _WAVE_GS_ENABLED
+    _WAVE_GS_ENABLED = bool(flag)
+
+
+def stencil_gs_available(A):
+    S = getattr(A, "stencil", None)
+    return bool(_PACKED_ENABLED and _STENCIL_ENABLED and _WAVE_GS_ENABLED and S is not None and S.gs_ok)
+
+
+def stencil_gs(A, x, b, sweeps=1):
+    """`sweeps` exact forward (lexicographic) Gauss-Seidel sweeps in place on x (lmg_stencil_gs_sweep): the
+    bits of csr_gs_schedule on the level schedule, without a schedule."""
+    _vec_ok(x, b)
+    S = A.stencil
+    if S is None or not S.gs_ok:
+        raise LmgError("stencil_gs needs a grid-stencil matrix without coupling across line ends")
+    if S._gs_work is None:
+        nb = int(_lib.lib().lmg_stencil_gs_work_bytes(S.n, S.W))
+        S._gs_work = torch.zeros((nb + 7) // 8, dtype=torch.int64, device=x.device)
+    if sweeps <= 0:
+        return
+    hv = None if S._hot_val is None else ctypes.addressof(S._hot_val)
+    check(_lib.lib().lmg_stencil_gs_sweep(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask, S.hot, hv,
+                                          _p(x), _p(b), _p(S._gs_work), int(sweeps), _s()), "lmg_stencil_gs_sweep")
+
+
+def stencil_gs_check(A):
+    """Raises if a band of the wavefront kernel ever gave up waiting for its predecessor (one D2H read)."""
+    S = A.stencil
+    if S is not None and S._gs_work is not None:
+        lines = (S.n + S.W - 1) // S.W
+        nbands = (lines + 63) // 64
+        if int(S._gs_work.view(torch.int32)[2 + nbands]):
+            raise LmgError("wavefront Gauss-Seidel: a band timed out waiting for the previous one")
 
 
 def gs_prepare(A, sched):

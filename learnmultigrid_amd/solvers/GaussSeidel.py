@@ -24,7 +24,10 @@ class GaussSeidel(IterativeSolver):
         A = self._device_matrix()
         n = self.dim
         import scipy.sparse as sp
-        sched = ops.build_gs_schedule(sp.csr_matrix(self.matrix), gs_mode, self._device)
+        if gs_mode == "lexicographic" and A.shape[0] >= 4096:
+            A.pack()                       # large grid operators: the wavefront kernel needs the stencil twin
+        wave = gs_mode == "lexicographic" and ops.stencil_gs_available(A)
+        sched = None if wave else ops.build_gs_schedule(sp.csr_matrix(self.matrix), gs_mode, self._device)
         b = self._to_device(self.rhs)
         x = torch.zeros(n, dtype=F64, device=self._device) if initial_guess is None \
             else self._to_device(initial_guess)
@@ -40,7 +43,10 @@ class GaussSeidel(IterativeSolver):
             if self.residual <= error:
                 self._log("Reached convergence Gauss")
                 break
-            ops.csr_gs_schedule(A, x, b, sched, 1)                     # :37
+            if wave:
+                ops.stencil_gs(A, x, b, 1)                             # :37, pipelined wavefront (gs_wave.hip)
+            else:
+                ops.csr_gs_schedule(A, x, b, sched, 1)                 # :37
         self.solution = self._column(x)
         self.residual_vector = self._column(r)
         self.track_res = np.array(track, dtype=float).reshape(-1, 1)

@@ -152,6 +152,101 @@ def test_gauss_seidel_lexicographic_bit_exact(name):
     assert np.all(lab[coo.row] != lab[coo.col])
 
 
+def _seven_point(m):
+    """Constant-coefficient 7-point operator {-W-1, -W, -1, 0, 1, W, W+1} (P1 stiffness of a uniform mesh of
+    sheared triangles) with identity boundary rows, columns untouched (like the reference's Dirichlet rows)."""
+    W = m + 1
+    n = W * W
+    idx = np.arange(n)
+    yy, xx = idx // W, idx % W
+    inter = (xx > 0) & (xx < m) & (yy > 0) & (yy < m)
+    rows, cols, vals = [idx[~inter]], [idx[~inter]], [np.ones((~inter).sum())]
+    for off, v in ((-W - 1, -0.5), (-W, -1.0), (-1, -1.0), (0, 6.25), (1, -1.0), (W, -1.0), (W + 1, -0.5)):
+        rows.append(idx[inter])
+        cols.append(idx[inter] + off)
+        vals.append(np.full(inter.sum(), v))
+    return K.as_csr(sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr())
+
+
+@pytest.mark.parametrize("name", ["poisson2d_129", "poisson2d_300", "galerkin_9pt", "galerkin_9pt_257", "poisson1d",
+                                  "with_empty_and_diagless_rows", "seven_point_150"])
+def test_wavefront_gauss_seidel_bit_exact(name):
+    """Exact forward Gauss-Seidel as a pipelined wavefront (gs_wave.hip: a wave per 64 grid lines, bands
+    handed over through memory) against pyamg's sweep restated in oracle/lmg_oracle.c, bitwise, over several
+    sweeps: one band and many, 5- / 7- / 9-point and 1-D, rows without a diagonal, empty rows."""
+    if name == "poisson2d_300":
+        A = K.as_csr(P.poisson_2d_structured(299)[0])
+    elif name == "galerkin_9pt_257":
+        Pm = P.tensor_interpolator_2d(513)
+        A = K.as_csr(sp.csr_matrix(Pm.T @ P.poisson_2d_structured(512)[0] @ Pm))
+    elif name == "seven_point_150":
+        A = _seven_point(149)
+    else:
+        A = rpat_case(name)
+    n = A.shape[0]
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    dA.pack()
+    assert dA.stencil is not None and dA.stencil.gs_ok and ops.stencil_gs_available(dA), name
+    if name == "seven_point_150":
+        assert dA.stencil.umask == 0x1BB
+    rng = np.random.default_rng(41)
+    x0, b = rng.standard_normal(n), rng.standard_normal(n)
+    want = x0.copy()
+    x = dev(x0.copy())
+    db = dev(b)
+    for sweeps in (1, 2, 3):
+        K.lib().orc_csr_gs_forward(n, A.indptr, A.indices, A.data, want, b, sweeps)
+        ops.stencil_gs(dA, x, db, sweeps)
+        got = x.cpu().numpy()
+        assert np.array_equal(got, want), (name, sweeps, np.flatnonzero(got != want)[:8])
+    ops.stencil_gs_check(dA)
+    # ... and the level-scheduled executors give the same bits (they stay the path of every other matrix)
+    try:
+        ops.set_wavefront_gs_enabled(False)
+        assert not ops.stencil_gs_available(dA)
+        pat = sp.csr_matrix((np.ones(A.nnz, dtype=np.int8), A.indices, A.indptr), shape=A.shape)
+        sched = ops.build_gs_schedule(pat, "lexicographic", DEV)
+        x2 = dev(x0.copy())
+        ops.csr_gs_schedule(dA, x2, db, sched, 6)
+        assert torch.equal(x2, x)
+    finally:
+        ops.set_wavefront_gs_enabled(True)
+
+
+def test_wavefront_gauss_seidel_refuses_coupling_across_line_ends():
+    # a 5-point-like operator whose rows in column 0 also reach i - 1 (the end of the previous line): the wavefront
+    # would need a value that is not computed yet, so the builder must send it to the level schedule
+    W, n = 12, 144
+    idx = np.arange(n)
+    rows, cols, vals = [], [], []
+    for off, v in ((-W, -1.0), (-1, -1.0), (0, 4.5), (1, -1.0), (W, -1.0)):
+        ok = (idx + off >= 0) & (idx + off < n)
+        rows.append(idx[ok]); cols.append(idx[ok] + off); vals.append(np.full(ok.sum(), v))
+    A = K.as_csr(sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr())
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    dA.pack()
+    assert dA.stencil is not None and not dA.stencil.gs_ok and not ops.stencil_gs_available(dA)
+    with pytest.raises(ops.LmgError):
+        ops.stencil_gs(dA, dev(np.zeros(n)), dev(np.ones(n)), 1)
+
+
+def test_wavefront_gauss_seidel_full_size_4097():
+    """One exact forward sweep on the 16.8 M-row fine level of cfg#4 (65 bands in flight) against the oracle."""
+    A = K.as_csr(P.poisson_2d_structured(4096)[0])
+    n = A.shape[0]
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    dA.pack()
+    assert ops.stencil_gs_available(dA)
+    rng = np.random.default_rng(4)
+    x0, b = rng.standard_normal(n), rng.standard_normal(n)
+    want = x0.copy()
+    K.lib().orc_csr_gs_forward(n, A.indptr, A.indices, A.data, want, b, 1)
+    x = dev(x0)
+    ops.stencil_gs(dA, x, dev(b), 1)
+    assert np.array_equal(x.cpu().numpy(), want)
+    ops.stencil_gs_check(dA)
+
+
 def test_gauss_seidel_ell_executor_and_its_fallbacks():
     """Medium schedules run on the pattern copy in schedule order (lmg_csr_gs_schedule_ell):
     same bits as the oracle, also after the VALUES changed (the copy only holds the pattern), and

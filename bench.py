@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--transfer", default="geometric", choices=["geometric", "learned"],
                     help="learned = row-stochastic perturbed L2-type Q per level (cfg#3/#5)")
     ap.add_argument("--rebuild", type=int, default=0, help="time this many numeric Galerkin rebuilds (cfg#5)")
+    ap.add_argument("--coarse", default="auto", choices=["auto", "dense", "banded", "bcr"], help="coarsest-level solver")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-tts", action="store_true", help="skip the time-to-solution leg")
     ap.add_argument("--no-packed", action="store_true", help="plain CSR kernels (no lossless twins at all)")
@@ -246,7 +247,7 @@ def main():
         n_loc_fine = D.fine_local_rows
     else:
         t0 = time.perf_counter()
-        H = Hierarchy(A, hier, dev)
+        H = Hierarchy(A, hier, dev, coarse_solver=args.coarse)
         torch.cuda.synchronize()
         setup_s = time.perf_counter() - t0
         fine = H.levels[0]

@@ -315,6 +315,19 @@ int lmg_dense_gemv(int64_t n, int64_t m, const double *d_M, const double *d_x, d
 int lmg_dense_gemv_blockdiag(int64_t nblocks, int64_t bs, const double *d_M, const double *d_x,
                              double *d_y, void *stream);
 
+/* Batched GEMV on windows of a vector, for block k < nblocks and row r < rows:
+ *     y[k*y_stride + r] = (d_z ? d_z[k*z_stride + r] : 0) + alpha * sum_c M[k][r][c] * x[k*x_stride + c]
+ * (M: nblocks dense rows x cols blocks, row-major; windows may overlap).  The building block of the
+ * block-cyclic-reduction coarse solver (coarse.py), which lifts the size limit of the dense / one-level
+ * banded solvers: `spsolve` on coarse operators of 10^5 unknowns (2-level runs, Multigrid.py:106).
+ * cols and x_stride even, M and x 16-byte aligned.  lmg_block_copy: dst[k*dst_stride + i] =
+ * src[k*src_stride + i], i < bs. */
+int lmg_dense_gemv_windows(int64_t nblocks, int64_t rows, int64_t cols, const double *d_M, const double *d_x,
+                           int64_t x_stride, const double *d_z, int64_t z_stride, double alpha, double *d_y,
+                           int64_t y_stride, void *stream);
+int lmg_block_copy(int64_t nblocks, int64_t bs, const double *d_src, int64_t src_stride, double *d_dst,
+                   int64_t dst_stride, void *stream);
+
 /* ---- Galerkin product (SpGEMM)  C = A * B -----------------------------------------
  * Replaces SciPy's csr_matmat behind `i.T @ A @ i` (Multigrid.py:97-98), evaluated as
  * (R A) P like SciPy does.  Row-wise Gustavson with an expand / stable-sort / in-order

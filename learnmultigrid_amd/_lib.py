@@ -73,6 +73,8 @@ SIGNATURES = {
     "lmg_scatter": (_c.c_int, [_i64, _p, _p, _p, _p]),
     "lmg_dense_gemv": (_c.c_int, [_i64, _i64, _p, _p, _p, _p]),
     "lmg_dense_gemv_blockdiag": (_c.c_int, [_i64, _i64, _p, _p, _p, _p]),
+    "lmg_dense_gemv_windows": (_c.c_int, [_i64, _i64, _i64, _p, _p, _i64, _p, _i64, _f64, _p, _i64, _p]),
+    "lmg_block_copy": (_c.c_int, [_i64, _i64, _p, _i64, _p, _i64, _p]),
     "lmg_spgemm_count": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p]),
     "lmg_spgemm_symbolic": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _i32, _p, _p]),
     "lmg_spgemm_numeric": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),

@@ -302,20 +302,207 @@ class BandedBlockSolver:
         return 8 * (2 * self.k * self.s * self.s + self.nS * self.nS)
 
 
+class BlockCyclicReduction:
+    """Exact block elimination of a banded operator by block cyclic reduction: the unknowns (in their
+    natural order, or in reverse Cuthill-McKee order when that is narrower) are cut into m blocks of b >=
+    half-bandwidth unknowns, which makes the operator block tridiagonal; every level eliminates the odd
+    blocks
+
+        x_i = D_i^-1 (b_i - L_i x_{i-1} - U_i x_{i+1})                                  (i odd)
+        D'_j = D_j - L_j D_{j-1}^-1 U_{j-1} - U_j D_{j+1}^-1 L_{j+1},  L'_j = -L_j D_{j-1}^-1 L_{j-1}, ...  (j even)
+
+    until one block is left (log2 m levels).  All inverses are formed explicitly at setup (batched GEMMs),
+    so an application is 3 batched GEMV launches per level on dense b x b / b x 2b blocks -- about 5 n b
+    doubles of HBM traffic and no sequential triangular solve: 257^2 unknowns of a 25-point operator
+    (b = 516) 1.4 GB, 513^2 (b = 1028) 11 GB.  This is what lifts the size limit of the other two solvers
+    for the scripts' 2-level runs (coarse `spsolve` on 66 k - 263 k unknowns, test/thesis_compare_2D.py:430-435).
+    No pivoting across blocks (like BandedBlockSolver); the caller's refinement step and dense_inverse's
+    own verification guard the accuracy."""
+    kind = "block-cyclic-reduction"
+
+    @staticmethod
+    def estimate_bytes(n, b):
+        m = -(-n // b)
+        tot = 0
+        while m > 1:
+            mo, me = m // 2, m - m // 2
+            tot += mo * b * b + me * 2 * b * b + mo * 2 * b * b
+            m = me
+        return 8 * (tot + b * b)
+
+    def __init__(self, A, ops_mod, perm=None, w=None):
+        self.ops = ops_mod
+        self._symbolic(A, perm, w)
+        self.factor(A)
+
+    def _symbolic(self, A, perm, w):
+        dev = A.device
+        n = A.shape[0]
+        rp, ci = A.rowptr.cpu().numpy(), A.colidx.cpu().numpy()
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))
+        cols = ci.astype(np.int64)
+        if perm is not None:
+            inv = np.empty(n, dtype=np.int64)
+            inv[np.asarray(perm, dtype=np.int64)] = np.arange(n)
+            rows, cols = inv[rows], inv[cols]
+        if w is None:
+            w = int(np.abs(rows - cols).max()) if cols.size else 1
+        b = max(int(w), 2)
+        b += b % 2
+        m = -(-n // b)
+        self.n, self.b, self.m, self.npad = n, b, m, m * b
+        I, J = rows // b, cols // b
+        if np.any(np.abs(I - J) > 1):
+            raise ValueError("block size below the bandwidth: the operator is not block tridiagonal")
+        t = lambda a, dt=torch.int64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+        loc = (rows % b) * b + (cols % b)
+        eid = np.arange(cols.size, dtype=np.int64)
+        self._maps = []
+        for d in (0, -1, 1):                                   # D, L (block column I-1), U (I+1)
+            msk = (J - I) == d
+            self._maps.append((t(eid[msk]), t(I[msk] * b * b + loc[msk])))
+        # padding rows (unknowns n .. npad-1) are identity rows
+        pad = np.arange(n, self.npad, dtype=np.int64)
+        self._pad_dst = t((pad // b) * b * b + (pad % b) * b + (pad % b))
+        self.perm = None if perm is None else t(perm, torch.int32)
+        self._nnz = int(cols.size)
+        # vectors of every level: right-hand sides B, D_odd^-1 b_odd C (one zero block in front and behind),
+        # solutions X (one zero block behind)
+        z = lambda k: torch.zeros(k * b, dtype=F64, device=dev)
+        self.B, self.C, self.X, sizes = [], [], [], []
+        mm = m
+        while True:
+            sizes.append(mm)
+            self.B.append(z(mm))
+            self.X.append(z(mm + 1))
+            if mm == 1:
+                break
+            self.C.append(z(mm // 2 + 2))
+            mm = mm - mm // 2
+        self.sizes = sizes
+        self.levels = []
+        self.root = None
+
+    def factor(self, A):
+        if A.nnz != self._nnz:
+            raise ValueError("coarse operator changed its sparsity pattern")
+        b, m = self.b, self.m
+        dev = A.vals.device
+        v = A.vals
+        stacks = []
+        for src, dst in self._maps:
+            st = torch.zeros(m * b * b, dtype=F64, device=dev)
+            st.index_put_((dst,), v[src], accumulate=True)
+            stacks.append(st)
+        stacks[0].index_put_((self._pad_dst,), torch.ones(self._pad_dst.numel(), dtype=F64, device=dev), accumulate=True)
+        D, L, U = (st.view(m, b, b) for st in stacks)
+        self.levels = []
+        while D.shape[0] > 1:
+            mm = D.shape[0]
+            mo, me = mm // 2, mm - mm // 2
+            Dinv = dense_inverse(D[1::2].contiguous())
+            Hm, Hp = torch.bmm(Dinv, L[1::2]), torch.bmm(Dinv, U[1::2])
+            Le, Ue = L[0::2], U[0::2]
+            zero = torch.zeros((1, b, b), dtype=F64, device=dev)
+            Hp_prev = torch.cat([zero, Hp], 0)[:me]                    # H+ of the odd block left of even block k
+            Hm_next = torch.cat([Hm, zero], 0)[:me]                    # H- of the odd block right of it
+            Dn = D[0::2] - torch.bmm(Le, Hp_prev) - torch.bmm(Ue, Hm_next)
+            Hm_prev = torch.cat([zero, Hm], 0)[:me]
+            Hp_next = torch.cat([Hp, zero], 0)[:me]
+            Ln = -torch.bmm(Le, Hm_prev)
+            Un = -torch.bmm(Ue, Hp_next)
+            self.levels.append((Dinv.contiguous(), torch.cat([Le, Ue], 2).contiguous(), torch.cat([Hm, Hp], 2).contiguous()))
+            D, L, U = Dn.contiguous(), Ln.contiguous(), Un.contiguous()
+        self.root = dense_inverse(D[0].contiguous()).view(1, b, b).contiguous()
+
+    def apply(self, rhs, x):
+        o, b, n = self.ops, self.b, self.n
+        B0 = self.B[0]
+        if self.perm is None:
+            o.copy(rhs, B0[:n])
+        else:
+            o.gather(self.perm, rhs, B0[:n])
+        for l, (Dinv, LU, _H) in enumerate(self.levels):
+            mm = self.sizes[l]
+            mo, me = mm // 2, mm - mm // 2
+            Bl, Cl, Bn = self.B[l], self.C[l], self.B[l + 1]
+            o.dense_gemv_windows(Dinv, Bl[b:], 2 * b, Cl[b:], b)                               # c_k = D^-1 b_(2k+1)
+            o.dense_gemv_windows(LU, Cl, b, Bn, b, z=Bl, z_stride=2 * b, alpha=-1.0)           # b'_k = b_2k - [L U][c_k-1; c_k]
+        last = len(self.levels)
+        o.dense_gemv_windows(self.root, self.B[last], b, self.X[last], b)
+        for l in range(last - 1, -1, -1):
+            mm = self.sizes[l]
+            mo, me = mm // 2, mm - mm // 2
+            Xl, Xn, Cl = self.X[l], self.X[l + 1], self.C[l]
+            H = self.levels[l][2]
+            o.dense_gemv_windows(H, Xn, b, Xl[b:], 2 * b, z=Cl[b:], z_stride=b, alpha=-1.0)     # odd blocks
+            o.block_copy(me, b, Xn, b, Xl, 2 * b)                                             # even blocks
+        if self.perm is None:
+            o.copy(self.X[0][:n], x)
+        else:
+            o.scatter(self.perm, self.X[0][:n], x)
+
+    def bytes_per_apply(self):
+        return 8 * (sum(int(t.numel()) for lev in self.levels for t in lev) + int(self.root.numel()))
+
+
+BANDED_MAX_BYTES = 1 << 30          # above this the one-level banded solver gives way to cyclic reduction
+DENSE_PREFERRED_BYTES = 256 << 20   # non-banded operators this small keep the plain dense inverse
+
+
+def _rcm_order(Ah):
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    pat = sp.csr_matrix((np.ones(Ah.nnz, dtype=np.int8), Ah.indices, Ah.indptr), shape=Ah.shape)
+    pat = (pat + pat.T).tocsr()
+    perm = np.asarray(reverse_cuthill_mckee(pat, symmetric_mode=True), dtype=np.int64)
+    inv = np.empty(perm.size, dtype=np.int64)
+    inv[perm] = np.arange(perm.size)
+    coo = Ah.tocoo()
+    w = int(np.abs(inv[coo.row] - inv[coo.col]).max()) if coo.nnz else 0
+    return perm, w
+
+
 def make_coarse_solver(A, ops_mod, strategy="auto"):
-    """strategy: "auto" | "dense" | "banded"."""
+    """strategy: "auto" | "dense" | "banded" | "bcr".
+    auto: dense inverse below 2048 unknowns; the one-level banded solver while its factors stay below 1 GB;
+    block cyclic reduction (natural or reverse Cuthill-McKee order, whichever is narrower) beyond that;
+    the dense inverse as the last resort (up to MAX_DENSE unknowns)."""
     n = A.shape[0]
-    if strategy not in ("auto", "dense", "banded"):
+    if strategy not in ("auto", "dense", "banded", "bcr"):
         raise ValueError("unknown coarse solver strategy %r" % (strategy,))
-    if strategy != "dense" and n >= 2048:
-        Ah = sp.csr_matrix((A.vals.cpu().numpy(), A.colidx.cpu().numpy(), A.rowptr.cpu().numpy()), shape=A.shape)
-        plan = BandedBlockSolver.plan(n, max(half_bandwidth(Ah), 1))
+    if strategy == "dense" or n < 2048 and strategy == "auto":
+        return DenseInverse(A, ops_mod)
+    Ah = sp.csr_matrix((A.vals.cpu().numpy(), A.colidx.cpu().numpy(), A.rowptr.cpu().numpy()), shape=A.shape)
+    w = max(half_bandwidth(Ah), 1)
+    if strategy in ("auto", "banded"):
+        plan = BandedBlockSolver.plan(n, w)
         if plan is not None:
-            try:
-                return BandedBlockSolver(A, ops_mod, *plan)
-            except (ValueError, RuntimeError):
-                if strategy == "banded":
-                    raise
+            k, s = plan
+            est = 8 * (2 * k * s * s + (n - k * s) ** 2)
+            if strategy == "banded" or est <= BANDED_MAX_BYTES:
+                try:
+                    return BandedBlockSolver(A, ops_mod, k, s)
+                except (ValueError, RuntimeError):
+                    if strategy == "banded":
+                        raise
         elif strategy == "banded":
             raise ValueError("operator is not narrow-banded: cannot use the banded coarse solver")
+    if strategy == "auto" and 8 * n * n <= DENSE_PREFERRED_BYTES:
+        return DenseInverse(A, ops_mod)                       # small and not banded: one GEMV beats 3 log2(m) launches
+    # block cyclic reduction, in the narrower of the natural and the reverse Cuthill-McKee ordering
+    perm, wr = (None, w)
+    if w > 4 * int(np.sqrt(n)) + 8:
+        p2, w2 = _rcm_order(Ah)
+        if w2 < w:
+            perm, wr = p2, max(w2, 1)
+    free = torch.cuda.mem_get_info(A.device)[0] if A.device.type == "cuda" else 1 << 62
+    est = BlockCyclicReduction.estimate_bytes(n, wr + wr % 2)
+    if 4 * wr <= n and 3 * est <= free:                       # (factor() holds about three copies while it runs)
+        try:
+            return BlockCyclicReduction(A, ops_mod, perm, wr)
+        except (ValueError, RuntimeError):
+            if strategy == "bcr":
+                raise
+    elif strategy == "bcr":
+        raise ValueError("block cyclic reduction does not fit: bandwidth %d of %d unknowns, %d MB" % (wr, n, est >> 20))
     return DenseInverse(A, ops_mod)

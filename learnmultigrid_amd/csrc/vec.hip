@@ -133,6 +133,45 @@ __global__ void __launch_bounds__(kBlock) dense_gemv_kernel(int64_t n, int64_t m
     }
 }
 
+// Batched GEMV on windows of a vector: for block k and row r
+//     y[k*ys + r] = (z ? z[k*zs + r] : 0) + alpha * sum_c M[k][r][c] * x[k*xs + c]
+// (M: nb dense rows x cols blocks, row-major, one after the other).  One wave per row, like
+// dense_gemv_kernel; the windows of neighbouring blocks may overlap (xs < cols).  This is the only
+// kernel of the block-cyclic-reduction coarse solver (coarse.py BlockCyclicReduction).
+__global__ void __launch_bounds__(kBlock) dense_gemv_windows_kernel(int64_t nb, int64_t rows, int64_t cols,
+                                                                    const double *M, const double *x0, int64_t xs,
+                                                                    const double *z0, int64_t zs, double alpha,
+                                                                    double *y0, int64_t ys)
+{
+    const int lane = threadIdx.x & (LMG_WAVE - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LMG_WAVE;
+    const int64_t nwaves = (int64_t)gridDim.x * kBlock / LMG_WAVE;
+    for (int64_t row = wave; row < nb * rows; row += nwaves) {
+        const int64_t k = row / rows, r = row - k * rows;
+        const double2 *M2 = reinterpret_cast<const double2 *>(M + row * cols);
+        const double2 *x2 = reinterpret_cast<const double2 *>(x0 + k * xs);
+        double s = 0.0;
+        for (int64_t j = lane; j < cols / 2; j += LMG_WAVE) {
+            const double2 mv = M2[j], xv = x2[j];
+            s += mv.x * xv.x;
+            s += mv.y * xv.y;
+        }
+        s = lmg_wave_sum(s);
+        if (lane == 0) y0[k * ys + r] = (z0 ? z0[k * zs + r] : 0.0) + alpha * s;
+    }
+}
+
+// dst[k*ds + i] = src[k*ss + i], i < bs: strided copy of whole blocks
+__global__ void __launch_bounds__(kBlock) block_copy_kernel(int64_t nb, int64_t bs, const double *src, int64_t ss,
+                                                            double *dst, int64_t ds)
+{
+    const int64_t total = nb * bs;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t k = i / bs, r = i - k * bs;
+        dst[k * ds + r] = src[k * ss + r];
+    }
+}
+
 // ---- exclusive scan (int32): per-block scan + block sums + add-back -------------------
 constexpr int kScanBlock = 1024;
 constexpr int kScanItems = 4;
@@ -349,6 +388,32 @@ int lmg_dense_gemv_blockdiag(int64_t nblocks, int64_t bs, const double *M, const
     if (!lmg_aligned16(M) || !lmg_aligned16(x) || (bs % 2)) return LMG_ERR_ALIGN;
     hipLaunchKernelGGL(dense_gemv_kernel, dim3(grid_for(nblocks * bs, kBlock / LMG_WAVE)), dim3(kBlock), 0,
                        lmg_stream(stream), nblocks * bs, bs, M, x, y, bs);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_dense_gemv_windows(int64_t nblocks, int64_t rows, int64_t cols, const double *M, const double *x,
+                           int64_t x_stride, const double *z, int64_t z_stride, double alpha, double *y,
+                           int64_t y_stride, void *stream)
+{
+    if (nblocks < 0 || rows < 0 || cols < 0 || x_stride < 0 || y_stride < rows || (z && z_stride < 0)) return LMG_ERR_ARG;
+    if (nblocks * rows == 0) return LMG_OK;
+    if (!M || !x || !y || x == y || z == y) return LMG_ERR_ARG;
+    if (!lmg_aligned16(M) || !lmg_aligned16(x) || (cols % 2) || (x_stride % 2)) return LMG_ERR_ALIGN;
+    hipLaunchKernelGGL(dense_gemv_windows_kernel, dim3(grid_for(nblocks * rows, kBlock / LMG_WAVE)), dim3(kBlock), 0,
+                       lmg_stream(stream), nblocks, rows, cols, M, x, x_stride, z, z_stride, alpha, y, y_stride);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_block_copy(int64_t nblocks, int64_t bs, const double *src, int64_t src_stride, double *dst,
+                   int64_t dst_stride, void *stream)
+{
+    if (nblocks < 0 || bs < 0 || src_stride < 0 || dst_stride < bs) return LMG_ERR_ARG;
+    if (nblocks * bs == 0) return LMG_OK;
+    if (!src || !dst) return LMG_ERR_ARG;
+    hipLaunchKernelGGL(block_copy_kernel, dim3(grid_for(nblocks * bs, kBlock)), dim3(kBlock), 0, lmg_stream(stream),
+                       nblocks, bs, src, src_stride, dst, dst_stride);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }

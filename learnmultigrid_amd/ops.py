@@ -909,6 +909,26 @@ def dense_gemv_blockdiag(M, x, y):
           "lmg_dense_gemv_blockdiag")
 
 
+def dense_gemv_windows(M, x, x_stride, y, y_stride, z=None, z_stride=0, alpha=1.0):
+    """y[k*ys + r] = (z[k*zs + r] if z else 0) + alpha * M[k, r, :] . x[k*xs : k*xs + cols]  for the
+    (nblocks, rows, cols) stack M; x, y, z are (views into) flat float64 vectors."""
+    _vec_ok(M, x, y, z)
+    nb, rows, cols = M.shape
+    need_x = (nb - 1) * x_stride + cols
+    if x.numel() < need_x or y.numel() < (nb - 1) * y_stride + rows or (z is not None and z.numel() < (nb - 1) * z_stride + rows):
+        raise ValueError("dense_gemv_windows: a window leaves its vector")
+    check(_lib.lib().lmg_dense_gemv_windows(nb, rows, cols, _p(M), _p(x), int(x_stride), _p(z), int(z_stride), float(alpha),
+                                            _p(y), int(y_stride), _s()), "lmg_dense_gemv_windows")
+
+
+def block_copy(nblocks, bs, src, src_stride, dst, dst_stride):
+    _vec_ok(src, dst)
+    if src.numel() < (nblocks - 1) * src_stride + bs or dst.numel() < (nblocks - 1) * dst_stride + bs:
+        raise ValueError("block_copy: a block leaves its vector")
+    check(_lib.lib().lmg_block_copy(int(nblocks), int(bs), _p(src), int(src_stride), _p(dst), int(dst_stride), _s()),
+          "lmg_block_copy")
+
+
 # ---- SpGEMM ---------------------------------------------------------------------------------
 def exclusive_scan_i32(inp, out):
     n = inp.numel()

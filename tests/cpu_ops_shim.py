@@ -108,6 +108,23 @@ def dense_gemv_blockdiag(M, x, y):
         _np(y)[i * s:(i + 1) * s] = K.dense_gemv(_np(M[i]), _np(x)[i * s:(i + 1) * s])
 
 
+def dense_gemv_windows(M, x, x_stride, y, y_stride, z=None, z_stride=0, alpha=1.0):
+    nb, rows, cols = M.shape
+    Mn, xn, yn = _np(M), _np(x), _np(y)
+    zn = None if z is None else _np(z)
+    out = [(zn[k * z_stride:k * z_stride + rows] if zn is not None else 0.0)
+           + alpha * K.dense_gemv(np.ascontiguousarray(Mn[k]), np.ascontiguousarray(xn[k * x_stride:k * x_stride + cols]))
+           for k in range(nb)]
+    for k in range(nb):
+        yn[k * y_stride:k * y_stride + rows] = out[k]
+
+
+def block_copy(nblocks, bs, src, src_stride, dst, dst_stride):
+    sn, dn = _np(src), _np(dst)
+    for k in range(nblocks):
+        dn[k * dst_stride:k * dst_stride + bs] = sn[k * src_stride:k * src_stride + bs]
+
+
 class SpGEMMPlan:
     def __init__(self, A, B, record="lazy"):
         self.shape = (A.shape[0], B.shape[1])

@@ -90,3 +90,71 @@ def test_unstructured_numbering_falls_back_to_dense():
     Ap = sp.csr_matrix(A[p][:, p])
     Ap.sort_indices()
     assert coarse.make_coarse_solver(DeviceCSR.from_scipy(Ap, "cpu"), shim).kind == "dense"
+
+
+def _l2_galerkin(side):
+    """25-point Galerkin operator of an L2-type (learned-like) transfer on a jittered 7-point fine operator:
+    what a 2-level learned-Q run hands to the coarse solver (half-bandwidth 2 * side + 2)."""
+    A, _ = P.jittered_poisson_2d(2 * (side - 1), seed=42)
+    l2 = P.pseudo_l2_interpolator_1d(2 * side - 1)
+    Q = P.learned_like(sp.kron(l2, l2).tocsr(), 43)
+    Ac = sp.csr_matrix(Q.T @ A @ Q)
+    Ac.sort_indices()
+    return Ac
+
+
+def test_block_cyclic_reduction_matches_superlu():
+    for Ac in (galerkin_operator(48), _l2_galerkin(41)):            # 9-point 49^2; 25-point 41^2 (odd block counts too)
+        n = Ac.shape[0]
+        dA = DeviceCSR.from_scipy(sp.csr_matrix(Ac), "cpu")
+        solver = coarse.make_coarse_solver(dA, shim, "bcr")
+        assert solver.kind == "block-cyclic-reduction" and solver.perm is None
+        assert solver.b >= coarse.half_bandwidth(Ac) and len(solver.levels) == int(np.ceil(np.log2(solver.m)))
+        assert solver.bytes_per_apply() <= coarse.BlockCyclicReduction.estimate_bytes(n, solver.b)
+        rng = np.random.default_rng(1)
+        b = rng.standard_normal(n)
+        x = torch.zeros(n, dtype=torch.float64)
+        solver.apply(torch.from_numpy(b.copy()), x)
+        want = spla.spsolve(sp.csc_matrix(Ac), b)
+        assert np.linalg.norm(x.numpy() - want) / np.linalg.norm(want) < 1e-10
+        d = torch.zeros(n, dtype=torch.float64)
+        solver.apply(torch.from_numpy(b - Ac @ x.numpy()), d)
+        assert np.linalg.norm(x.numpy() + d.numpy() - want) / np.linalg.norm(want) < 1e-13
+        # new values on the same pattern: numeric phase only
+        A2 = Ac.copy()
+        A2.data = A2.data * (1.0 + 0.1 * rng.random(A2.nnz))
+        A2 = sp.csr_matrix(A2 + sp.identity(n) * abs(A2).sum(1).max())           # keep it nonsingular
+        A2 = sp.csr_matrix((A2.data, A2.indices, A2.indptr), shape=A2.shape)
+        if A2.nnz == Ac.nnz:
+            d2 = DeviceCSR.from_scipy(A2, "cpu")
+            solver.factor(d2)
+            solver.apply(torch.from_numpy(b.copy()), x)
+            want2 = spla.spsolve(sp.csc_matrix(A2), b)
+            assert np.linalg.norm(x.numpy() - want2) / np.linalg.norm(want2) < 1e-10
+
+
+def test_block_cyclic_reduction_reorders_scrambled_operators():
+    Ac = galerkin_operator(40)
+    n = Ac.shape[0]
+    rng = np.random.default_rng(3)
+    p = rng.permutation(n)
+    As = sp.csr_matrix(Ac[p][:, p])                                    # same operator, numbering destroyed
+    As.sort_indices()
+    assert coarse.half_bandwidth(As) > n // 2
+    dA = DeviceCSR.from_scipy(As, "cpu")
+    solver = coarse.make_coarse_solver(dA, shim, "bcr")
+    assert solver.kind == "block-cyclic-reduction" and solver.perm is not None and solver.b < 6 * 41
+    b = rng.standard_normal(n)
+    x = torch.zeros(n, dtype=torch.float64)
+    solver.apply(torch.from_numpy(b.copy()), x)
+    want = spla.spsolve(sp.csc_matrix(As), b)
+    assert np.linalg.norm(x.numpy() - want) / np.linalg.norm(want) < 1e-10
+
+
+def test_auto_strategy_switches_to_cyclic_reduction_when_banded_factors_get_large(monkeypatch):
+    Ac = galerkin_operator(64)
+    dA = DeviceCSR.from_scipy(Ac, "cpu")
+    assert coarse.make_coarse_solver(dA, shim, "auto").kind == "banded-block"
+    monkeypatch.setattr(coarse, "BANDED_MAX_BYTES", 1 << 20)
+    monkeypatch.setattr(coarse, "DENSE_PREFERRED_BYTES", 1 << 20)
+    assert coarse.make_coarse_solver(dA, shim, "auto").kind == "block-cyclic-reduction"

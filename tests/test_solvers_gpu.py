@@ -454,6 +454,30 @@ def test_cfg5_style_variable_coefficient_rebuild_and_solve():
     np.testing.assert_allclose(got[1:], want[1:], rtol=1e-10)           # (entry 0 is the sqrt(n) quirk)
 
 
+def test_two_level_learned_q_with_a_large_coarse_level():
+    """The scripts' default shape -- SemiGeometricMG(A, rhs, Q).solve(levels=2, smoother="GaussSeidel",
+    smooth_steps=3, error=1e-10) on a 2-D problem (test/test_B_patch.py:193-194, test/thesis_compare_2D.py:430-435)
+    -- at a size where the coarse `spsolve` (Multigrid.py:106) sees 257^2 = 66 049 unknowns of a 25-point operator:
+    too large for a dense inverse, 4 GB for the one-level banded solver, 1.4 GB for block cyclic reduction.
+    Jittered triangulation (7-point fine operator, all-distinct values), learned-like L2-type Q; histories
+    against the CPU oracle (which re-factorises with SuperLU in every cycle, like the reference)."""
+    m = 512
+    A, rhs = P.jittered_poisson_2d(m, seed=42)
+    l2 = P.pseudo_l2_interpolator_1d(m + 1)
+    Q = P.learned_like(sp.kron(l2, l2).tocsr(), 43)
+    assert Q.shape == (513 * 513, 257 * 257)
+    kw = dict(levels=2, smoother="GaussSeidel", smooth_steps=3, error=1e-10, max_iterations=4)
+    mg = SemiGeometricMG(A, rhs.copy(), Q)
+    mg.solve(**kw)
+    assert mg._hier.coarse.kind == "block-cyclic-reduction" and mg.level_dims == [513 * 513, 257 * 257]
+    assert mg._hier.coarse.bytes_per_apply() < 2 << 30
+    ref = V.RefMultigrid(A, rhs.copy(), l2_proj=Q)
+    ref.solve(**kw)
+    assert mg.get_iterations() == ref.iterations
+    assert_track(mg.get_track_res(), ref.track_res)
+    np.testing.assert_allclose(mg.get_solution(), ref.solution, rtol=1e-8, atol=1e-12)
+
+
 def test_cfg5_full_size_8193():
     """BASELINE config #5 at FULL size on one GPU: 8193^2 = 67 125 249 DoF variable-coefficient stiffness
     (nnz = 335 M, close to the int32 limit), learned-like Q, 7 levels, ~25 GB resident plus the 32.7 GB

@@ -234,6 +234,19 @@ int lmg_value_encode(int64_t count, const double *d_vals, const double *d_dict, 
 int lmg_csr_inverse_diagonal(int64_t n, const int32_t *d_rowptr, const int32_t *d_colidx, const double *d_vals,
                              double *d_dinv, void *stream);
 
+/* CSR transpose by counting sort (setup: the restriction R = P^T as an explicit CSR, `i.T` of
+ * Multigrid.py:93).  lmg_csr_transpose_count: d_counts[c] (zeroed by the caller, ncols entries) += number of
+ * entries in column c; the caller scans d_counts into d_t_rowptr with lmg_exclusive_scan_i32;
+ * lmg_csr_transpose_fill places every entry (d_cursor: ncols zeroed int32) and sorts each row of A^T by
+ * column, so the result equals SciPy's A.T.tocsr() for a sorted, duplicate-free A.  Rows of A^T longer than
+ * lmg_csr_transpose_max_row() entries are sorted by a one-thread insertion sort too (slow): callers with
+ * such rows use a library sort instead (ops.DeviceCSR.transpose does). */
+int lmg_csr_transpose_max_row(void);
+int lmg_csr_transpose_count(int64_t nnz, int64_t ncols, const int32_t *d_colidx, int32_t *d_counts, void *stream);
+int lmg_csr_transpose_fill(int64_t n, int64_t ncols, const int32_t *d_rowptr, const int32_t *d_colidx,
+                           const double *d_vals, const int32_t *d_t_rowptr, int32_t *d_cursor, int32_t *d_t_colidx,
+                           double *d_t_vals, void *stream);
+
 /* ---- Gauss-Seidel ---------------------------------------------------------------
  * One independent set: for every i in d_rows, in place,
  *     x_i = (b_i - sum_{j != i} a_ij x_j) / a_ii      (skipped when a_ii == 0)
@@ -327,6 +340,14 @@ int lmg_dense_gemv_windows(int64_t nblocks, int64_t rows, int64_t cols, const do
                            int64_t y_stride, void *stream);
 int lmg_block_copy(int64_t nblocks, int64_t bs, const double *d_src, int64_t src_stride, double *d_dst,
                    int64_t dst_stride, void *stream);
+
+/* Inverses of nmat dense n x n matrices (n <= 128, row-major, one after the other): one workgroup per
+ * matrix, Gauss-Jordan with partial pivoting in LDS.  d_info[k] = 1 when matrix k has an exactly zero
+ * pivot (d_Ainv of that matrix is then undefined).  Setup-time helper of the coarse solvers. */
+/* d_dense (n x m, row-major, zeroed by the caller) += the CSR matrix (duplicate entries are summed). */
+int lmg_csr_to_dense(int64_t n, int64_t m, const int32_t *d_rowptr, const int32_t *d_colidx, const double *d_vals,
+                     double *d_dense, void *stream);
+int lmg_batched_inverse(int64_t nmat, int32_t n, const double *d_A, double *d_Ainv, int32_t *d_info, void *stream);
 
 /* ---- Galerkin product (SpGEMM)  C = A * B -----------------------------------------
  * Replaces SciPy's csr_matmat behind `i.T @ A @ i` (Multigrid.py:97-98), evaluated as

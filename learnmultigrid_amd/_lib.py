@@ -56,6 +56,9 @@ SIGNATURES = {
     "lmg_value_set_insert": (_c.c_int, [_i64, _p, _p, _i64, _i32, _p, _p]),
     "lmg_value_encode": (_c.c_int, [_i64, _p, _p, _i32, _c.c_int, _p, _p, _p]),
     "lmg_csr_inverse_diagonal": (_c.c_int, [_i64, _p, _p, _p, _p, _p]),
+    "lmg_csr_transpose_max_row": (_c.c_int, []),
+    "lmg_csr_transpose_count": (_c.c_int, [_i64, _i64, _p, _p, _p]),
+    "lmg_csr_transpose_fill": (_c.c_int, [_i64, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     "lmg_csr_gs_rows": (_c.c_int, [_p, _p, _p, _p, _p, _p, _i64, _p]),
     "lmg_csr_gs_schedule": (_c.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _c.c_int, _p]),
     "lmg_csr_gs_schedule_ell": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _p, _i64, _c.c_int, _p]),
@@ -75,6 +78,8 @@ SIGNATURES = {
     "lmg_dense_gemv_blockdiag": (_c.c_int, [_i64, _i64, _p, _p, _p, _p]),
     "lmg_dense_gemv_windows": (_c.c_int, [_i64, _i64, _i64, _p, _p, _i64, _p, _i64, _f64, _p, _i64, _p]),
     "lmg_block_copy": (_c.c_int, [_i64, _i64, _p, _i64, _p, _i64, _p]),
+    "lmg_csr_to_dense": (_c.c_int, [_i64, _i64, _p, _p, _p, _p, _p]),
+    "lmg_batched_inverse": (_c.c_int, [_i64, _i32, _p, _p, _p, _p]),
     "lmg_spgemm_count": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p]),
     "lmg_spgemm_symbolic": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _i32, _p, _p]),
     "lmg_spgemm_numeric": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),

@@ -37,8 +37,12 @@ _INV_LEAF = 512
 def csr_to_dense(A):
     n, m = A.shape
     dense = torch.zeros((n, m), dtype=F64, device=A.device)
+    if A.vals.is_cuda:
+        from . import ops as _ops
+        _ops.csr_to_dense(A, dense)
+        return dense
     rows = torch.repeat_interleave(torch.arange(n, device=A.device), (A.rowptr[1:] - A.rowptr[:-1]).long())
-    dense.index_put_((rows, A.colidx.long()), A.vals, accumulate=True)
+    dense.index_put_((rows, A.colidx.long()), A.vals, accumulate=True)      # (duplicates are summed: non-canonical input)
     return dense
 
 
@@ -48,6 +52,14 @@ def _inv_schur(A, leaf=_INV_LEAF):
     verify the result (dense_inverse)."""
     n = A.shape[-1]
     if n <= leaf:
+        if A.is_cuda and n <= 128:
+            # own batched Gauss-Jordan kernel: no rocSOLVER (thousands of small panel launches, and 0.4 s to
+            # load the library in a fresh process)
+            from . import ops as _ops
+            M = _ops.batched_inverse(A.reshape(-1, n, n))
+            if M is None:
+                raise RuntimeError("singular leaf")
+            return M.reshape(A.shape)
         return torch.linalg.inv(A)
     h = n // 2
     A11, A12, A21, A22 = A[..., :h, :h], A[..., :h, h:], A[..., h:, :h], A[..., h:, h:]
@@ -84,7 +96,7 @@ def dense_inverse(dense, polish=2, tol=1e-9):
 
     M = None
     try:
-        M = _inv_schur(dense, 128 if dense.dim() == 3 else _INV_LEAF)
+        M = _inv_schur(dense, 128 if (dense.dim() == 3 or dense.is_cuda) else _INV_LEAF)
     except RuntimeError:                              # a singular leaf
         M = None
     if good(M):
@@ -208,27 +220,30 @@ class BandedBlockSolver:
         cw = int((we - ws).max())
         self.cw = cw
         t = lambda a, dt=torch.int64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
-        self._src_II = t(eid[m])
-        self._dst_II = t((pr[m] // s) * s * s + (pr[m] % s) * s + (pc[m] % s))
+        if max(k * s * s, k * s * cw, nS * nS, cols.size) >= 2 ** 31:
+            raise ValueError("banded coarse solver: dense factors beyond int32 indexing")
+        t32 = lambda a: t(a, torch.int32)
+        self._src_II = t32(eid[m])
+        self._dst_II = t32((pr[m] // s) * s * s + (pr[m] % s) * s + (pc[m] % s))
         m = rI & ~cI                                  # A_IS: strip rows x separator columns
         strip = pr[m] // s
         loc = (pc[m] - nI) - ws[strip]
         if np.any(loc < 0) or np.any(loc >= (we - ws)[strip]):
             raise ValueError("a strip couples to a distant separator: not banded in this ordering")
-        self._src_IS = t(eid[m])
-        self._dst_IS = t(strip * s * cw + (pr[m] % s) * cw + loc)
+        self._src_IS = t32(eid[m])
+        self._dst_IS = t32(strip * s * cw + (pr[m] % s) * cw + loc)
         IS_pat = sp.csr_matrix((eid[m] + 1.0, (pr[m], pc[m] - nI)), shape=(nI, nS))
         m = ~rI & cI                                  # A_SI: separator rows x strip columns
         strip = pc[m] // s
         loc = (pr[m] - nI) - ws[strip]
         if np.any(loc < 0) or np.any(loc >= (we - ws)[strip]):
             raise ValueError("a strip couples to a distant separator: not banded in this ordering")
-        self._src_SI = t(eid[m])
-        self._dst_SI = t(strip * cw * s + loc * s + (pc[m] % s))
+        self._src_SI = t32(eid[m])
+        self._dst_SI = t32(strip * cw * s + loc * s + (pc[m] % s))
         SI_pat = sp.csr_matrix((eid[m] + 1.0, (pr[m] - nI, pc[m])), shape=(nS, nI))
         m = ~rI & ~cI
-        self._src_SS = t(eid[m])
-        self._dst_SS = t((pr[m] - nI) * nS + (pc[m] - nI))
+        self._src_SS = t32(eid[m])
+        self._dst_SS = t32((pr[m] - nI) * nS + (pc[m] - nI))
         # where the k local Schur updates land in S (flat indices, padded entries masked out)
         ar = np.arange(cw, dtype=np.int64)
         gi = ws[:, None, None] + ar[None, :, None]
@@ -242,10 +257,10 @@ class BandedBlockSolver:
         for parity in (0, 1):
             sel = ok.copy()
             sel[np.arange(k) % 2 != parity] = False
-            self._upd.append((t(flat[sel]), t(dst[sel])))
+            self._upd.append((t32(flat[sel]), t32(dst[sel])))
         # sparse off-diagonal blocks for apply(): CSR patterns once, values refreshed by factor()
-        self._IS_src = t(np.rint(IS_pat.data).astype(np.int64) - 1)
-        self._SI_src = t(np.rint(SI_pat.data).astype(np.int64) - 1)
+        self._IS_src = t32(np.rint(IS_pat.data).astype(np.int64) - 1)
+        self._SI_src = t32(np.rint(SI_pat.data).astype(np.int64) - 1)
         z64 = lambda m_: torch.zeros(m_, dtype=F64, device=dev)
         self.A_IS = DeviceCSR(t(IS_pat.indptr, torch.int32), t(IS_pat.indices, torch.int32), z64(IS_pat.nnz), (nI, nS))
         self.A_SI = DeviceCSR(t(SI_pat.indptr, torch.int32), t(SI_pat.indices, torch.int32), z64(SI_pat.nnz), (nS, nI))
@@ -256,6 +271,16 @@ class BandedBlockSolver:
         self._nnz = int(cols.size)
 
     # ---- numeric: device only (repeated for every Galerkin rebuild) -----------------------
+    def _place(self, v, src, dst, size):
+        """zeros(size) with out[dst[k]] = v[src[k]] (destinations are distinct: sorted, duplicate-free CSR) --
+        own gather / scatter kernels: torch's index_put_ costs 0.4 s to load in a fresh process."""
+        out = torch.zeros(size, dtype=F64, device=v.device)
+        if src.numel():
+            tmp = torch.empty(src.numel(), dtype=F64, device=v.device)
+            self.ops.gather(src, v, tmp)
+            self.ops.scatter(dst, tmp, out)
+        return out
+
     def factor(self, A):
         """Strip inverses, Schur complement S = A_SS - A_SI A_II^-1 A_IS and S^-1 from the
         current values of A (same pattern as at construction)."""
@@ -264,23 +289,24 @@ class BandedBlockSolver:
         k, s, cw, nS = self.k, self.s, self.cw, self.nS
         dev = A.vals.device
         v = A.vals
-        dense = torch.zeros(k * s * s, dtype=F64, device=dev)
-        dense.index_put_((self._dst_II,), v[self._src_II], accumulate=True)
-        dense = dense.view(k, s, s)
+        dense = self._place(v, self._src_II, self._dst_II, k * s * s).view(k, s, s)
         self.blocks = dense_inverse(dense)            # all strips as one batch
-        ais = torch.zeros(k * s * cw, dtype=F64, device=dev)
-        ais.index_put_((self._dst_IS,), v[self._src_IS], accumulate=True)
-        asi = torch.zeros(k * cw * s, dtype=F64, device=dev)
-        asi.index_put_((self._dst_SI,), v[self._src_SI], accumulate=True)
+        ais = self._place(v, self._src_IS, self._dst_IS, k * s * cw)
+        asi = self._place(v, self._src_SI, self._dst_SI, k * cw * s)
         upd = torch.bmm(asi.view(k, cw, s), torch.bmm(self.blocks, ais.view(k, s, cw)))      # k x cw x cw
-        Sc = torch.zeros(nS * nS, dtype=F64, device=dev)
-        Sc.index_put_((self._dst_SS,), v[self._src_SS], accumulate=True)
+        Sc = self._place(v, self._src_SS, self._dst_SS, nS * nS)
         upd = upd.reshape(-1)
-        for sel, dst in self._upd:
-            Sc.index_put_((dst,), -upd[sel], accumulate=True)
+        for sel, dst in self._upd:                       # S[dst] -= upd[sel], every destination once per pass
+            if sel.numel():
+                tmp = torch.empty(sel.numel(), dtype=F64, device=dev)
+                cur = torch.empty(sel.numel(), dtype=F64, device=dev)
+                self.ops.gather(sel, upd, tmp)
+                self.ops.gather(dst, Sc, cur)
+                self.ops.axpby(-1.0, tmp, 1.0, cur)
+                self.ops.scatter(dst, cur, Sc)
         self.Sinv = dense_inverse(Sc.view(nS, nS))
-        self.A_IS.vals.copy_(v[self._IS_src])
-        self.A_SI.vals.copy_(v[self._SI_src])
+        self.ops.gather(self._IS_src, v, self.A_IS.vals)
+        self.ops.gather(self._SI_src, v, self.A_SI.vals)
         self.A_IS.invalidate_packed()
         self.A_SI.invalidate_packed()
 
@@ -358,12 +384,14 @@ class BlockCyclicReduction:
         loc = (rows % b) * b + (cols % b)
         eid = np.arange(cols.size, dtype=np.int64)
         self._maps = []
+        if m * b * b >= 2 ** 31:
+            raise ValueError("block cyclic reduction: dense blocks beyond int32 indexing")
         for d in (0, -1, 1):                                   # D, L (block column I-1), U (I+1)
             msk = (J - I) == d
-            self._maps.append((t(eid[msk]), t(I[msk] * b * b + loc[msk])))
+            self._maps.append((t(eid[msk], torch.int32), t(I[msk] * b * b + loc[msk], torch.int32)))
         # padding rows (unknowns n .. npad-1) are identity rows
         pad = np.arange(n, self.npad, dtype=np.int64)
-        self._pad_dst = t((pad // b) * b * b + (pad % b) * b + (pad % b))
+        self._pad_dst = t((pad // b) * b * b + (pad % b) * b + (pad % b), torch.int32)
         self.perm = None if perm is None else t(perm, torch.int32)
         self._nnz = int(cols.size)
         # vectors of every level: right-hand sides B, D_odd^-1 b_odd C (one zero block in front and behind),
@@ -392,9 +420,13 @@ class BlockCyclicReduction:
         stacks = []
         for src, dst in self._maps:
             st = torch.zeros(m * b * b, dtype=F64, device=dev)
-            st.index_put_((dst,), v[src], accumulate=True)
+            if src.numel():
+                tmp = torch.empty(src.numel(), dtype=F64, device=dev)
+                self.ops.gather(src, v, tmp)
+                self.ops.scatter(dst, tmp, st)
             stacks.append(st)
-        stacks[0].index_put_((self._pad_dst,), torch.ones(self._pad_dst.numel(), dtype=F64, device=dev), accumulate=True)
+        if self._pad_dst.numel():
+            self.ops.scatter(self._pad_dst, torch.ones(self._pad_dst.numel(), dtype=F64, device=dev), stacks[0])
         D, L, U = (st.view(m, b, b) for st in stacks)
         self.levels = []
         while D.shape[0] > 1:

@@ -161,6 +161,14 @@ __global__ void __launch_bounds__(kBlock) dense_gemv_windows_kernel(int64_t nb, 
     }
 }
 
+// dense[i][colidx[e]] += vals[e] for the entries e of row i (dense zero-initialised by the caller)
+__global__ void __launch_bounds__(kBlock) csr_to_dense_kernel(int64_t n, int64_t m, const int *rowptr, const int *colidx,
+                                                              const double *vals, double *dense)
+{
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) dense[i * m + colidx[e]] += vals[e];
+}
+
 // dst[k*ds + i] = src[k*ss + i], i < bs: strided copy of whole blocks
 __global__ void __launch_bounds__(kBlock) block_copy_kernel(int64_t nb, int64_t bs, const double *src, int64_t ss,
                                                             double *dst, int64_t ds)
@@ -170,6 +178,92 @@ __global__ void __launch_bounds__(kBlock) block_copy_kernel(int64_t nb, int64_t 
         const int64_t k = i / bs, r = i - k * bs;
         dst[k * ds + r] = src[k * ss + r];
     }
+}
+
+// Batched inverse of small dense matrices (n <= 128): one workgroup per matrix, the matrix in LDS,
+// in-place Gauss-Jordan with partial pivoting (row swaps recorded, undone as column swaps at the end).
+// Setup-time helper of the coarse solvers (the leaves of coarse.py's block Schur recursion): replaces
+// thousands of 25-50 us rocSOLVER getf2 panel launches -- and the 0.4 s it takes to load that library
+// in a fresh process -- by one launch.  info[k] = 1 when a pivot of matrix k is exactly zero.
+constexpr int kInvMax = 128;
+__global__ void __launch_bounds__(kBlock) batched_inverse_kernel(int n, const double *A, double *Ainv, int *info)
+{
+    extern __shared__ double s_a[];                  // n rows of stride n + 1
+    __shared__ int s_piv[kInvMax];
+    __shared__ int s_p;
+    __shared__ double s_red_v[kBlock / LMG_WAVE];
+    __shared__ int s_red_i[kBlock / LMG_WAVE];
+    const int ld = n + 1, t = threadIdx.x;
+    const double *Ak = A + (int64_t)blockIdx.x * n * n;
+    for (int e = t; e < n * n; e += kBlock) s_a[(e / n) * ld + e % n] = Ak[e];
+    __syncthreads();
+    bool singular = false;
+    for (int k = 0; k < n; ++k) {
+        // pivot: largest |a[i][k]|, i >= k (ties: smallest i)
+        double best = -1.0;
+        int bi = k;
+        for (int i = k + t; i < n; i += kBlock) {
+            const double v = fabs(s_a[i * ld + k]);
+            if (v > best) { best = v; bi = i; }
+        }
+#pragma unroll
+        for (int off = LMG_WAVE / 2; off > 0; off >>= 1) {
+            const double ov = __shfl_down(best, off, LMG_WAVE);
+            const int oi = __shfl_down(bi, off, LMG_WAVE);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if ((t & (LMG_WAVE - 1)) == 0) { s_red_v[t / LMG_WAVE] = best; s_red_i[t / LMG_WAVE] = bi; }
+        __syncthreads();
+        if (t == 0) {
+            for (int w = 1; w < kBlock / LMG_WAVE; ++w)
+                if (s_red_v[w] > best || (s_red_v[w] == best && s_red_i[w] < bi)) { best = s_red_v[w]; bi = s_red_i[w]; }
+            s_p = bi;
+            s_piv[k] = bi;
+        }
+        __syncthreads();
+        const int p = s_p;
+        if (p != k)
+            for (int j = t; j < n; j += kBlock) {
+                const double tmp = s_a[k * ld + j];
+                s_a[k * ld + j] = s_a[p * ld + j];
+                s_a[p * ld + j] = tmp;
+            }
+        __syncthreads();
+        const double piv = s_a[k * ld + k];
+        if (piv == 0.0) { singular = true; break; }          // uniform: every thread reads the same LDS word
+        __syncthreads();
+        for (int j = t; j < n; j += kBlock) s_a[k * ld + j] = (j == k ? 1.0 : s_a[k * ld + j]) / piv;
+        __syncthreads();
+        // eliminate column k from every other row; a[i][k] becomes -f * (1 / piv)
+        for (int e = t; e < n * n; e += kBlock) {
+            const int i = e / n, j = e - i * n;
+            if (i == k) continue;
+            const double f = s_a[i * ld + k];
+            if (j == k) continue;
+            s_a[i * ld + j] -= f * s_a[k * ld + j];
+        }
+        __syncthreads();
+        for (int i = t; i < n; i += kBlock)
+            if (i != k) s_a[i * ld + k] = -s_a[i * ld + k] * s_a[k * ld + k];
+        __syncthreads();
+    }
+    if (singular) {
+        if (t == 0) info[blockIdx.x] = 1;
+        return;
+    }
+    for (int k = n - 1; k >= 0; --k) {               // undo the row swaps: swap COLUMNS k and piv[k]
+        const int p = s_piv[k];
+        if (p != k)
+            for (int i = t; i < n; i += kBlock) {
+                const double tmp = s_a[i * ld + k];
+                s_a[i * ld + k] = s_a[i * ld + p];
+                s_a[i * ld + p] = tmp;
+            }
+        __syncthreads();
+    }
+    double *Ok = Ainv + (int64_t)blockIdx.x * n * n;
+    for (int e = t; e < n * n; e += kBlock) Ok[e] = s_a[(e / n) * ld + e % n];
+    if (t == 0) info[blockIdx.x] = 0;
 }
 
 // ---- exclusive scan (int32): per-block scan + block sums + add-back -------------------
@@ -402,6 +496,33 @@ int lmg_dense_gemv_windows(int64_t nblocks, int64_t rows, int64_t cols, const do
     if (!lmg_aligned16(M) || !lmg_aligned16(x) || (cols % 2) || (x_stride % 2)) return LMG_ERR_ALIGN;
     hipLaunchKernelGGL(dense_gemv_windows_kernel, dim3(grid_for(nblocks * rows, kBlock / LMG_WAVE)), dim3(kBlock), 0,
                        lmg_stream(stream), nblocks, rows, cols, M, x, x_stride, z, z_stride, alpha, y, y_stride);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_csr_to_dense(int64_t n, int64_t m, const int32_t *rowptr, const int32_t *colidx, const double *vals,
+                     double *dense, void *stream)
+{
+    if (n < 0 || m < 0) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    if (!rowptr || !dense) return LMG_ERR_ARG;
+    hipLaunchKernelGGL(csr_to_dense_kernel, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, lmg_stream(stream), n, m, rowptr,
+                       colidx, vals, dense);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_batched_inverse(int64_t nmat, int32_t n, const double *A, double *Ainv, int32_t *info, void *stream)
+{
+    if (nmat < 0 || n < 1 || n > kInvMax) return LMG_ERR_ARG;
+    if (nmat == 0) return LMG_OK;
+    if (!A || !Ainv || !info || A == Ainv) return LMG_ERR_ARG;
+    const size_t lds = (size_t)n * (n + 1) * sizeof(double);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(batched_inverse_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kInvMax * (kInvMax + 1) * sizeof(double)));
+    hipLaunchKernelGGL(batched_inverse_kernel, dim3((unsigned)nmat), dim3(kBlock), lds, lmg_stream(stream), (int)n, A, Ainv,
+                       info);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }

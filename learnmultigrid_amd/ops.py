@@ -129,6 +129,21 @@ class DeviceCSR:
         `A.T.tocsr()` gives for a canonical A."""
         n, m = self.shape
         dev = self.vals.device
+        if self.vals.is_cuda and self.nnz and self.nnz < 2 ** 31 - 1:
+            # counting sort on the column indices (csrc/transpose.hip): no library sort, whose code takes
+            # 0.3 s to load in a fresh process
+            L = _lib.lib()
+            counts = torch.zeros(m, dtype=I32, device=dev)
+            check(L.lmg_csr_transpose_count(self.nnz, m, _p(self.colidx), _p(counts), _s()), "lmg_csr_transpose_count")
+            if int(counts.max()) <= int(L.lmg_csr_transpose_max_row()):
+                rp = torch.empty(m + 1, dtype=I32, device=dev)
+                exclusive_scan_i32(counts, rp)
+                counts.zero_()
+                tc = torch.empty(self.nnz, dtype=I32, device=dev)
+                tv = torch.empty(self.nnz, dtype=F64, device=dev)
+                check(L.lmg_csr_transpose_fill(n, m, _p(self.rowptr), _p(self.colidx), _p(self.vals), _p(rp), _p(counts),
+                                               _p(tc), _p(tv), _s()), "lmg_csr_transpose_fill")
+                return DeviceCSR(rp, tc, tv, (m, n))
         rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=I32),
                                        (self.rowptr[1:] - self.rowptr[:-1]).long())
         order = torch.sort(self.colidx, stable=True).indices
@@ -919,6 +934,25 @@ def dense_gemv_windows(M, x, x_stride, y, y_stride, z=None, z_stride=0, alpha=1.
         raise ValueError("dense_gemv_windows: a window leaves its vector")
     check(_lib.lib().lmg_dense_gemv_windows(nb, rows, cols, _p(M), _p(x), int(x_stride), _p(z), int(z_stride), float(alpha),
                                             _p(y), int(y_stride), _s()), "lmg_dense_gemv_windows")
+
+
+def csr_to_dense(A, dense):
+    check(_lib.lib().lmg_csr_to_dense(A.shape[0], A.shape[1], _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(dense), _s()),
+          "lmg_csr_to_dense")
+
+
+BATCHED_INVERSE_MAX = 128
+
+
+def batched_inverse(A):
+    """Inverses of a stack (nmat, n, n) of small dense matrices, n <= 128 (lmg_batched_inverse: Gauss-Jordan
+    with partial pivoting, one workgroup per matrix); None when a pivot is exactly zero."""
+    A = A.contiguous()
+    nmat, n, _ = A.shape
+    out = torch.empty_like(A)
+    info = torch.zeros(max(nmat, 1), dtype=I32, device=A.device)
+    check(_lib.lib().lmg_batched_inverse(nmat, n, _p(A), _p(out), _p(info), _s()), "lmg_batched_inverse")
+    return None if bool(info.any()) else out
 
 
 def block_copy(nblocks, bs, src, src_stride, dst, dst_stride):

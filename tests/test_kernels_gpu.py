@@ -334,6 +334,45 @@ def test_gauss_seidel_multicolor_matches_cpu_twin(name):
     assert np.array_equal(dx2.cpu().numpy(), w2)
 
 
+@pytest.mark.parametrize("name", ["prolong_65", "restrict_65", "l2like_restrict", "ragged_1000", "poisson2d_513",
+                                  "dense_rows"])
+def test_device_transpose_equals_scipy(name):
+    """R = P^T by counting sort on the device (csrc/transpose.hip; the library-sort path for rows longer than
+    the insertion sort takes): indices and values identical to SciPy's A.T.tocsr()."""
+    if name == "dense_rows":                       # dense 1-D transfer: rows of A^T with ~1000 entries -> library sort
+        A = K.as_csr(sp.csr_matrix(np.random.default_rng(2).standard_normal((1030, 515))))
+    else:
+        A = case(name)
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    T = dA.transpose()
+    want = sp.csr_matrix(A.T)
+    want.sort_indices()
+    assert T.shape == want.shape and T.nnz == want.nnz
+    assert np.array_equal(T.rowptr.cpu().numpy(), want.indptr)
+    assert np.array_equal(T.colidx.cpu().numpy(), want.indices)
+    assert np.array_equal(T.vals.cpu().numpy(), want.data)
+    T2 = dA.transpose()                            # deterministic although the fill uses atomics
+    assert torch.equal(T2.colidx, T.colidx) and torch.equal(T2.vals, T.vals)
+
+
+@pytest.mark.parametrize("n,nmat", [(1, 3), (7, 5), (64, 40), (71, 192), (128, 9)])
+def test_batched_inverse(n, nmat):
+    rng = np.random.default_rng(n)
+    A = rng.standard_normal((nmat, n, n))
+    A[0] = np.eye(n)[::-1]                         # a permutation: every pivot needs a row swap
+    if nmat > 1 and n > 2:
+        A[1, 0, 0] = 0.0                           # zero leading entry
+    M = ops.batched_inverse(dev(A))
+    assert M is not None
+    got = M.cpu().numpy()
+    for k in range(nmat):
+        assert np.abs(got[k] @ A[k] - np.eye(n)).max() < 1e-9 * max(1.0, np.linalg.cond(A[k]))
+    np.testing.assert_allclose(got, np.linalg.inv(A), rtol=1e-7, atol=1e-9)
+    S = A.copy()
+    S[nmat // 2] = 0.0
+    assert ops.batched_inverse(dev(S)) is None     # exactly singular: reported, not returned
+
+
 def test_vector_ops():
     rng = np.random.default_rng(10)
     for n in (1, 2, 3, 1000, 1 << 20 | 1):

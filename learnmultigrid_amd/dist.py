@@ -455,12 +455,28 @@ class DistributedVCycle:
         return np.concatenate(parts)
 
     # ---- the cycle ---------------------------------------------------------------------------------------
-    def _smooth(self, d, steps, omega, x_is_zero=False, deep=False, exchanged=False):
+    def _smooth(self, d, steps, omega, x_is_zero=False, deep=False, exchanged=False, want_residual=False):
         """`steps` Jacobi sweeps on the whole local block.  deep: the ghosts of x (of b when the
         iterate starts from zero) are exchanged ONCE (not at all when the caller knows they are
         exact: `exchanged`); sweep k is then exact up to ghost layer halo_depth - k, which is all
-        the next sweep needs.  Otherwise one exchange per sweep."""
+        the next sweep needs.  Otherwise one exchange per sweep.
+        Returns True when d.r = b - A x was produced along the way (fused pass, want_residual)."""
         o = self.ops
+        fused = getattr(o, "stencil_smooth_available", None)
+        if deep and steps > 0 and fused is not None and fused(d.A):
+            # no message between the sweeps: they (and the residual) run as fused passes over the local
+            # block -- the same bits as one launch per sweep (lmg_stencil_smooth)
+            if not exchanged:
+                self.exchange(d, d.b if x_is_zero else d.x)
+            left, zero = steps, x_is_zero
+            while left > 0:
+                k = min(left, o.FUSED_MAX_SWEEPS)
+                left -= k
+                o.stencil_smooth(d.A, None if zero else d.x, d.b, omega, k, d.tmp,
+                                 d.r if (want_residual and left == 0) else None)
+                d.x, d.tmp = d.tmp, d.x
+                zero = False
+            return want_residual
         if x_is_zero and steps > 0:
             if deep and not exchanged:
                 self.exchange(d, d.b)
@@ -477,6 +493,7 @@ class DistributedVCycle:
                 self.exchange(d, d.x)
             o.csr_jacobi(d.A, d.x, d.b, omega, d.tmp)
             d.x, d.tmp = d.tmp, d.x
+        return False
 
     def cycle(self, smoother, steps, omega=1.0, l=0, x_is_zero=False):
         """One V-cycle from level l down.  Returns the number of ghost layers on which this level's
@@ -490,10 +507,11 @@ class DistributedVCycle:
         # nu sweeps + the residual on the ghost layers the restriction reads consume nu + 1 + r_need
         # layers of one exchange; otherwise (deeper cycles, wide transfers) exchange before every use
         deep = steps >= 1 and steps + 1 + max(1, self.r_need[l]) <= D
-        self._smooth(d, steps, omega, x_is_zero, deep)
+        have_r = self._smooth(d, steps, omega, x_is_zero, deep, want_residual=True)
         if not deep:
             self.exchange(d, d.x)
-        o.csr_residual_norm2(d.A, d.x, d.b, d.r, None, None)
+        if not have_r:
+            o.csr_residual_norm2(d.A, d.x, d.b, d.r, None, None)
         if not deep:
             self.exchange(d, d.r)
         # The prolongation is applied on the ghost layers too (real P rows there).  The iterate is

@@ -55,12 +55,16 @@ def test_world1_nccl_path_matches_single_gpu_bitwise():
         dist.destroy_process_group()
 
 
-def _gpu_worker(rank, world, port, out_dir, transfer="geometric"):
+def _gpu_worker(rank, world, port, out_dir, transfer="geometric", fuse_all=False):
     import os
     import sys
     import torch.distributed as dist
     from conftest import ROOT
     sys.path.insert(0, ROOT)
+    if fuse_all:
+        # the product fuses the sweeps of a level only from 4 M rows on; force it on these small blocks
+        from learnmultigrid_amd import ops as _ops
+        _ops.FUSED_MIN_ROWS = 0
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -134,6 +138,17 @@ def test_several_ranks_on_one_gpu_match_single_gpu_bitwise(tmp_path, world):
     import torch.multiprocessing as mp
     mp.spawn(_gpu_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
+        ok = np.load(os.path.join(str(tmp_path), "ok_%d.npy" % r))
+        assert ok.all(), (r, ok)
+
+
+def test_two_ranks_with_fused_smoothing_passes_match_single_gpu_bitwise(tmp_path):
+    """The ranks' sweeps (and the residual) as fused passes over the local blocks with ghost layers
+    (what a rank runs from 4 M local rows on: N = 2, 4 at cfg#4): same bits as the single-GPU cycle."""
+    import os
+    import torch.multiprocessing as mp
+    mp.spawn(_gpu_worker, args=(2, _free_port(), str(tmp_path), "geometric", True), nprocs=2, join=True)
+    for r in range(2):
         ok = np.load(os.path.join(str(tmp_path), "ok_%d.npy" % r))
         assert ok.all(), (r, ok)
 

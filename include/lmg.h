@@ -421,6 +421,19 @@ int lmg_p1_assemble_2d(int64_t n_nodes, const double *d_px, const double *d_py, 
                        const int32_t *d_colidx, double *d_a_vals, double *d_m_vals, double *d_rhs,
                        void *stream);
 
+/* ---- 1-D L2-projection coupling operator (the step before the hot path) -------------------------
+ * B[i][j] = integral of fine basis i x coarse basis j over the intersections of fine and coarse elements, by
+ * the reference's 3-point rule; replaces Intersection.find_intersections1d (Intersection.py:60-76, an
+ * O(ne * ne_c) double loop) + CouplingOperator.compute_b_1d (CouplingOperator.py:32-69) and the row
+ * scalings of L2Projection.py:74-90.  d_xf / d_xc: strictly increasing node coordinates (nf, nc >= 2).
+ * lmg_l2_coupling_count: entries per row; the caller scans them into d_rowptr (lmg_exclusive_scan_i32);
+ * lmg_l2_coupling_fill writes sorted CSR rows.  kind 0: B; 1: "pseudo" Q = diag(colsum M_fine)^-1 B;
+ * 2: "quasi" Q = B / rowsum(B).  ("L2", Q = M^-1 B, is dense and stays on the host.) */
+int lmg_l2_coupling_count(int64_t nf, int64_t nc, const double *d_xf, const double *d_xc, int32_t *d_rownnz,
+                          void *stream);
+int lmg_l2_coupling_fill(int kind, int64_t nf, int64_t nc, const double *d_xf, const double *d_xc,
+                         const int32_t *d_rowptr, int32_t *d_colidx, double *d_vals, void *stream);
+
 /* ---- hipGraph capture of a launch sequence (one V-cycle) -----------------------------
  * begin/end bracket launches issued on `stream`; end returns an opaque executable graph. */
 int lmg_graph_begin(void *stream);

@@ -89,6 +89,8 @@ SIGNATURES = {
     "lmg_scan_scratch_count": (_i64, [_i64]),
     "lmg_exclusive_scan_i32": (_c.c_int, [_i64, _p, _p, _p, _p]),
     "lmg_p1_assemble_2d": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _p, _p, _f64, _p, _p, _p, _p, _p, _p]),
+    "lmg_l2_coupling_count": (_c.c_int, [_i64, _i64, _p, _p, _p, _p]),
+    "lmg_l2_coupling_fill": (_c.c_int, [_c.c_int, _i64, _i64, _p, _p, _p, _p, _p, _p]),
     "lmg_graph_begin": (_c.c_int, [_p]),
     "lmg_graph_end": (_c.c_int, [_p, _c.POINTER(_p)]),
     "lmg_graph_launch": (_c.c_int, [_p, _p]),

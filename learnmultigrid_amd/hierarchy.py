@@ -37,7 +37,7 @@ def _to_csr_host(M):
 
 class Level:
     __slots__ = ("n", "A", "P", "R", "x", "b", "r", "tmp", "plan_RA", "plan_RAP", "RA",
-                 "gs_sched", "host_pattern", "dinv")
+                 "gs_sched", "host_pattern", "dinv", "M", "plan_RM", "plan_RMP", "RM")
 
     def __init__(self, A):
         self.n = A.shape[0]
@@ -52,13 +52,18 @@ class Level:
         self.gs_sched = {}
         self.host_pattern = None
         self.dinv = None
+        self.M = None                  # mass matrix of the level (optional, see Hierarchy(mass=...))
+        self.plan_RM = self.plan_RMP = self.RM = None
 
 
 class Hierarchy:
     """levels[0] is the fine grid; transfers[l] (n_l x n_{l+1}) prolongates level l+1 -> l."""
 
     def __init__(self, A, transfers, device, coarse_refine=1, verbose=False, ops_mod=None,
-                 use_packed=True, coarse_solver="auto", spgemm_record="lazy"):
+                 use_packed=True, coarse_solver="auto", spgemm_record="lazy", mass=None):
+        """mass: optional fine-level mass matrix; every level then also gets M_(l+1) = Q_l^T M_l Q_l by the
+        same device SpGEMM (`M_coarse = i.T @ M @ i`, Multigrid.py:273-275, and `mass = Q.T @ mass @ Q` of
+        NeuralMG_2D.define_hierarchy, :763): levels[l].M, refreshed by rebuild_mass_numeric()."""
         # `ops_mod` exists for the CPU-only host-logic tests (a test shim stands in for the
         # HIP kernels); the product always runs with learnmultigrid_amd.ops.
         self.ops = ops if ops_mod is None else ops_mod
@@ -72,6 +77,10 @@ class Hierarchy:
         self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         A0 = A if isinstance(A, DeviceCSR) else DeviceCSR.from_scipy(A, self.device)
         self.levels = [Level(A0)]
+        if mass is not None:
+            self.levels[0].M = mass if isinstance(mass, DeviceCSR) else DeviceCSR.from_scipy(_to_csr_host(mass), self.device)
+            if self.levels[0].M.shape != A0.shape:
+                raise ValueError("mass matrix %s does not match the operator %s" % (self.levels[0].M.shape, A0.shape))
         for P in transfers:
             lev = self.levels[-1]
             Ph = _to_csr_host(P)
@@ -85,6 +94,11 @@ class Hierarchy:
             lev.plan_RAP = ops_.SpGEMMPlan(lev.RA, lev.P, spgemm_record)
             Ac = lev.plan_RAP.numeric(lev.RA, lev.P)
             self.levels.append(Level(Ac))
+            if lev.M is not None:
+                lev.plan_RM = ops_.SpGEMMPlan(lev.R, lev.M, spgemm_record)
+                lev.RM = lev.plan_RM.numeric(lev.R, lev.M)
+                lev.plan_RMP = ops_.SpGEMMPlan(lev.RM, lev.P, spgemm_record)
+                self.levels[-1].M = lev.plan_RMP.numeric(lev.RM, lev.P)
         self.use_packed = bool(use_packed)
         self._pack_all()
         self._inverse_diagonals()
@@ -144,6 +158,17 @@ class Hierarchy:
         self._inverse_diagonals()
         self._factor_coarsest()
         self._graphs = {}
+
+    def rebuild_mass_numeric(self, new_vals):
+        """New values of the fine mass matrix on the same pattern: numeric SpGEMM passes only."""
+        M0 = self.levels[0].M
+        if M0 is None or new_vals.numel() != M0.nnz:
+            raise ValueError("rebuild_mass_numeric needs a hierarchy built with mass= and the same sparsity pattern")
+        M0.vals.copy_(new_vals)
+        for l in range(len(self.levels) - 1):
+            lev = self.levels[l]
+            lev.plan_RM.numeric(lev.R, lev.M, out=lev.RM)
+            lev.plan_RMP.numeric(lev.RM, lev.P, out=self.levels[l + 1].M)
 
     def gs_schedule(self, l, kind):
         lev = self.levels[l]

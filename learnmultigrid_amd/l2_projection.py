@@ -69,3 +69,32 @@ def transfer_1d(kind, x_fine, x_coarse):
     if kind == "L2":
         return sp.csr_matrix(spla.spsolve(sp.csc_matrix(M), sp.csc_matrix(B)))
     raise ValueError("Invalid order %r (L2 | pseudo | quasi)" % (kind,))
+
+
+def transfer_1d_device(kind, x_fine, x_coarse, device):
+    """The same Q on an MI355X (csrc/l2proj.hip: one thread per fine node, segments by binary search,
+    rows in CSR): kind in B | pseudo | quasi ("L2" is a dense M^-1 B: use transfer_1d).  Returns an
+    ops.DeviceCSR; nodes must be strictly increasing."""
+    import torch
+    from . import ops, _lib
+    code = {"B": 0, "pseudo": 1, "quasi": 2}.get(kind)
+    if code is None:
+        raise ValueError("device transfer: kind must be B | pseudo | quasi, got %r" % (kind,))
+    xf = np.ascontiguousarray(np.asarray(x_fine, dtype=np.float64).ravel())
+    xc = np.ascontiguousarray(np.asarray(x_coarse, dtype=np.float64).ravel())
+    if xf.size < 2 or xc.size < 2 or np.any(np.diff(xf) <= 0) or np.any(np.diff(xc) <= 0):
+        raise ValueError("node coordinates must be strictly increasing (at least two nodes per mesh)")
+    dxf, dxc = torch.from_numpy(xf).to(device), torch.from_numpy(xc).to(device)
+    nf, nc = xf.size, xc.size
+    L = _lib.lib()
+    s = torch.cuda.current_stream(dxf.device).cuda_stream
+    rownnz = torch.empty(nf, dtype=torch.int32, device=device)
+    _lib.check(L.lmg_l2_coupling_count(nf, nc, dxf.data_ptr(), dxc.data_ptr(), rownnz.data_ptr(), s), "lmg_l2_coupling_count")
+    rowptr = torch.empty(nf + 1, dtype=torch.int32, device=device)
+    ops.exclusive_scan_i32(rownnz, rowptr)
+    nnz = int(rowptr[-1])
+    colidx = torch.empty(nnz, dtype=torch.int32, device=device)
+    vals = torch.empty(nnz, dtype=torch.float64, device=device)
+    _lib.check(L.lmg_l2_coupling_fill(code, nf, nc, dxf.data_ptr(), dxc.data_ptr(), rowptr.data_ptr(), colidx.data_ptr(),
+                                      vals.data_ptr(), s), "lmg_l2_coupling_fill")
+    return ops.DeviceCSR(rowptr, colidx, vals, (nf, nc))

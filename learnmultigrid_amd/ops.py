@@ -1169,5 +1169,112 @@ def register_torch_ops():
     lib.impl("csr_jacobi", op_jacobi, "CUDA")
     lib.impl("csr_spmv", op_spmv, "CUDA")
     lib.impl("csr_gs_rows_", op_gs_rows_, "CUDA")
+
+    # ---- the rest of the C ABI: Galerkin SpGEMM, coarse GEMV, and operators with their lossless twins --------
+    lib.define("spgemm(Tensor a_rowptr, Tensor a_colidx, Tensor a_vals, int a_cols, Tensor b_rowptr, Tensor b_colidx, "
+               "Tensor b_vals, int b_cols) -> (Tensor, Tensor, Tensor)")
+    lib.define("csr_transpose(Tensor rowptr, Tensor colidx, Tensor vals, int ncols) -> (Tensor, Tensor, Tensor)")
+    lib.define("dense_gemv(Tensor M, Tensor x) -> Tensor")
+    # an operator handle owns the packed / row-pattern / stencil / sliced-ELL twin built once by pack()
+    lib.define("operator_create(Tensor rowptr, Tensor colidx, Tensor vals, int ncols) -> int")
+    lib.define("operator_format(int handle) -> str")
+    lib.define("operator_free(int handle) -> ()")
+    lib.define("operator_spmv(int handle, Tensor x) -> Tensor")
+    lib.define("operator_residual(int handle, Tensor x, Tensor b) -> (Tensor, Tensor)")
+    lib.define("operator_jacobi(int handle, Tensor x, Tensor b, float omega, int sweeps) -> Tensor")
+    lib.define("operator_gauss_seidel_(int handle, Tensor(a!) x, Tensor b, int sweeps) -> ()")
+
+    def op_spgemm(arp, aci, ava, acols, brp, bci, bva, bcols):
+        C = spgemm(_csr(arp, aci, ava, acols), _csr(brp, bci, bva, bcols))
+        return C.rowptr, C.colidx, C.vals
+
+    def op_transpose(rowptr, colidx, vals, ncols):
+        T = _csr(rowptr, colidx, vals, ncols).transpose()
+        return T.rowptr, T.colidx, T.vals
+
+    def op_dense_gemv(M, x):
+        y = torch.empty(M.shape[0], dtype=F64, device=x.device)
+        dense_gemv(M.contiguous(), x, y)
+        return y
+
+    handles = register_torch_ops._handles = {}
+
+    def op_create(rowptr, colidx, vals, ncols):
+        A = _csr(rowptr, colidx, vals, ncols)
+        A.pack()
+        h = 1 + max(handles, default=0)
+        handles[h] = {"A": A, "gs": None}
+        return h
+
+    def _get(h):
+        if h not in handles:
+            raise LmgError("unknown operator handle %d" % h)
+        return handles[h]
+
+    def op_format(h):
+        A = _get(h)["A"]
+        return ("stencil" if A.stencil is not None else "rpat" if A.patterns is not None else
+                "sell" if A.sell is not None else "pcsr" if A.packed is not None else "csr")
+
+    def op_free(h):
+        handles.pop(h, None)
+
+    def op_h_spmv(h, x):
+        A = _get(h)["A"]
+        y = torch.empty(A.shape[0], dtype=F64, device=x.device)
+        csr_spmv(A, x, y, 1.0, 0.0)
+        return y
+
+    def op_h_residual(h, x, b):
+        A = _get(h)["A"]
+        r = torch.empty_like(b)
+        part = torch.empty(partials_count(A.shape[0]), dtype=F64, device=x.device)
+        n2 = torch.empty(1, dtype=F64, device=x.device)
+        csr_residual_norm2(A, x, b, r, part, n2)
+        return r, n2
+
+    def op_h_jacobi(h, x, b, omega, sweeps):
+        A = _get(h)["A"]
+        cur, out = x, torch.empty_like(x)
+        spare = None
+        left = int(sweeps)
+        while left > 0:
+            if A.stencil is not None and stencil_smooth_available(A):
+                k = min(left, FUSED_MAX_SWEEPS)
+                stencil_smooth(A, cur, b, omega, k, out)
+            else:
+                k = 1
+                csr_jacobi(A, cur, b, omega, out)
+            left -= k
+            if left > 0:
+                nxt = spare if spare is not None else torch.empty_like(x)
+                spare = cur if cur is not x else None
+                cur, out = out, nxt
+            else:
+                cur = out
+        return cur if sweeps > 0 else x.clone()
+
+    def op_h_gs_(h, x, b, sweeps):
+        ent = _get(h)
+        A = ent["A"]
+        if stencil_gs_available(A):
+            stencil_gs(A, x, b, int(sweeps))
+            return
+        if ent["gs"] is None:
+            import scipy.sparse as sp
+            pat = sp.csr_matrix((np.ones(A.nnz, dtype=np.int8), A.colidx.cpu().numpy(), A.rowptr.cpu().numpy()), shape=A.shape)
+            ent["gs"] = build_gs_schedule(pat, "lexicographic", A.device)
+        csr_gs_schedule(A, x, b, ent["gs"], int(sweeps))
+
+    lib.impl("spgemm", op_spgemm, "CUDA")
+    lib.impl("csr_transpose", op_transpose, "CUDA")
+    lib.impl("dense_gemv", op_dense_gemv, "CUDA")
+    lib.impl("operator_create", op_create, "CUDA")
+    lib.impl("operator_format", op_format, "CompositeExplicitAutograd")
+    lib.impl("operator_free", op_free, "CompositeExplicitAutograd")
+    lib.impl("operator_spmv", op_h_spmv, "CUDA")
+    lib.impl("operator_residual", op_h_residual, "CUDA")
+    lib.impl("operator_jacobi", op_h_jacobi, "CUDA")
+    lib.impl("operator_gauss_seidel_", op_h_gs_, "CUDA")
     register_torch_ops._lib = lib        # keep alive
     _registered = True

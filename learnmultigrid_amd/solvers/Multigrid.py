@@ -261,12 +261,16 @@ class NeuralMG(Multigrid):
 
     def _transfers(self, levels, first_call):
         out = []
-        M = np.asarray(self.M.todense()) if hasattr(self.M, "todense") else np.asarray(self.M)
+        M = sp.csr_matrix(self.M)
         for _ in range(levels - 1):
             if M.shape[0] % 2 == 0:
                 raise ValueError("mass matrix of even size %d: the learned 1-D transfer needs odd sizes "
                                  "(test/test_B_patch.py:52-53)" % M.shape[0])
-            Q = self.transfer_op(M)
-            out.append(sp.csr_matrix(Q))
-            M = np.asarray(sp.csr_matrix(Q.T @ M @ Q).toarray())                    # :273-275
+            Q = sp.csr_matrix(self.transfer_op(np.asarray(M.toarray())))
+            out.append(Q)
+            # M_coarse = Q^T M Q (:273-275) by the device SpGEMM, evaluated (Q^T M) Q like SciPy does: the
+            # same bits as the host product without forming dense n x n matrices for it
+            dQ = ops.DeviceCSR.from_scipy(Q, self._device)
+            dM = ops.DeviceCSR.from_scipy(M, self._device)
+            M = ops.spgemm(ops.spgemm(dQ.transpose(), dM), dQ).to_scipy()
         return out

@@ -59,3 +59,49 @@ def test_jittered_variable_coefficient_mesh_and_determinism():
     mg.solve(levels=4, smoother="Jacobi", smooth_steps=3, max_iterations=30, error=1e-9,
              smoother_semantics="as_named", omega=0.8)
     assert mg.get_residual() <= 1e-9
+
+
+# ---- 1-D L2-projection coupling operator on the device (csrc/l2proj.hip) ---------------------------
+@pytest.mark.parametrize("ne", [16, 64, 1024])
+def test_l2_projection_device_regular_nested(ne):
+    """Q "pseudo" / "quasi" of L2Projection(...).compute_transfer_1d() (L2Projection.py:74-90) built by the HIP
+    kernels against the operators the reference itself produced (goldens g2), and B against the host restatement."""
+    from conftest import load_golden, coo_from
+    from learnmultigrid_amd import l2_projection as L2
+    g = load_golden("g2_poisson1d_ne%d" % ne)
+    xf, xc = np.linspace(0, 1, ne + 1), np.linspace(0, 1, ne // 2 + 1)
+    for kind in ("pseudo", "quasi"):
+        Q = L2.transfer_1d_device(kind, xf, xc, "cuda:0").to_scipy()
+        assert abs(Q - coo_from(g, "Q_" + kind)).max() <= 1e-13, kind
+        assert Q.has_sorted_indices and np.diff(Q.indptr).max() <= 3
+    B = L2.transfer_1d_device("B", xf, xc, "cuda:0").to_scipy()
+    assert abs(B - L2.coupling_operator_1d(xf, xc)).max() <= 1e-16
+
+
+@pytest.mark.parametrize("case", ["g3_ne32", "g3_ne256", "non_nested", "coarse_finer_than_fine"])
+def test_l2_projection_device_irregular(case):
+    from conftest import load_golden, coo_from
+    from learnmultigrid_amd import l2_projection as L2
+    rng = np.random.default_rng(9)
+    if case.startswith("g3"):
+        g = load_golden("g3_fem1d_" + case[3:])
+        xf = g["x"]
+        xc = xf[0::2]
+    elif case == "non_nested":                       # no coincident interior nodes at all
+        xf = np.sort(np.concatenate([[0.0, 1.0], rng.random(300)]))
+        xc = np.sort(np.concatenate([[0.0, 1.0], rng.random(77)]))
+    else:                                            # locally the "coarse" mesh is the finer one: long rows of B
+        xf = np.sort(np.concatenate([[0.0, 1.0], rng.random(20)]))
+        xc = np.sort(np.concatenate([[0.0, 1.0], rng.random(400)]))
+    for kind in ("B", "pseudo", "quasi"):
+        got = L2.transfer_1d_device(kind, xf, xc, "cuda:0").to_scipy()
+        want = L2.coupling_operator_1d(xf, xc) if kind == "B" else L2.transfer_1d(kind, xf, xc)
+        assert abs(got - want).max() <= 1e-13 * max(1.0, abs(want).max()), (case, kind)
+    if case.startswith("g3"):
+        Q = L2.transfer_1d_device("quasi", xf, xc, "cuda:0").to_scipy()
+        assert abs(Q - coo_from(g, "Q_quasi")).max() <= 1e-13
+        np.testing.assert_allclose(np.asarray(Q.sum(axis=1)).ravel(), 1.0, rtol=1e-13)
+    with pytest.raises(ValueError):
+        L2.transfer_1d_device("L2", xf, xc, "cuda:0")
+    with pytest.raises(ValueError):
+        L2.transfer_1d_device("quasi", xf[::-1], xc, "cuda:0")

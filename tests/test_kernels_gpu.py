@@ -578,6 +578,43 @@ def test_torch_custom_ops_registered():
     assert np.array_equal(r.cpu().numpy(), wr)
     y = torch.ops.lmg.csr_spmv(dA.rowptr, dA.colidx, dA.vals, A.shape[1], x)
     assert np.array_equal(y.cpu().numpy(), A @ x.cpu().numpy())
+    # Galerkin product, transpose and coarse GEMV as custom ops
+    Pm = K.as_csr(P.tensor_interpolator_2d(33))
+    dP = ops.DeviceCSR.from_scipy(Pm, DEV)
+    trp, tci, tva = torch.ops.lmg.csr_transpose(dP.rowptr, dP.colidx, dP.vals, Pm.shape[1])
+    Rm = sp.csr_matrix(Pm.T)
+    Rm.sort_indices()
+    assert np.array_equal(tci.cpu().numpy(), Rm.indices) and np.array_equal(tva.cpu().numpy(), Rm.data)
+    crp, cci, cva = torch.ops.lmg.spgemm(trp, tci, tva, Pm.shape[0], dA.rowptr, dA.colidx, dA.vals, A.shape[1])
+    C = sp.csr_matrix((cva.cpu().numpy(), cci.cpu().numpy(), crp.cpu().numpy()), shape=(Pm.shape[1], A.shape[1]))
+    assert C.has_sorted_indices and abs(C - Rm @ A).max() == 0        # (SciPy drops products that cancel to 0.0)
+    Md = np.random.default_rng(5).standard_normal((40, A.shape[0]))
+    np.testing.assert_allclose(torch.ops.lmg.dense_gemv(dev(Md), x).cpu().numpy(), Md @ x.cpu().numpy(), rtol=1e-13)
+    # operators with their lossless twins behind a handle: sweeps, fused sweeps, exact Gauss-Seidel
+    h = torch.ops.lmg.operator_create(dA.rowptr, dA.colidx, dA.vals, A.shape[1])
+    assert torch.ops.lmg.operator_format(h) == "stencil"
+    xn, bn = x.cpu().numpy(), b.ravel()
+    assert np.array_equal(torch.ops.lmg.operator_spmv(h, x).cpu().numpy(), K.spmv(A, xn, np.zeros_like(xn), 1.0, 0.0))
+    r2, _ = torch.ops.lmg.operator_residual(h, x, dev(bn))
+    assert np.array_equal(r2.cpu().numpy(), wr)
+    want = xn
+    for _ in range(5):
+        want = K.jacobi(A, want, bn, 0.8)
+    min_rows = ops.FUSED_MIN_ROWS
+    try:
+        for ops.FUSED_MIN_ROWS in (min_rows, 0):                     # one launch per sweep / fused passes
+            got = torch.ops.lmg.operator_jacobi(h, x, dev(bn), 0.8, 5)
+            assert np.array_equal(got.cpu().numpy(), want)
+    finally:
+        ops.FUSED_MIN_ROWS = min_rows
+    xg = x.clone()
+    torch.ops.lmg.operator_gauss_seidel_(h, xg, dev(bn), 2)
+    wg = xn.copy()
+    K.gs_forward(A, wg, bn, 2)
+    assert np.array_equal(xg.cpu().numpy(), wg)
+    torch.ops.lmg.operator_free(h)
+    with pytest.raises(Exception):
+        torch.ops.lmg.operator_spmv(h, x)
 
 
 # ---- packed CSR (lmg_pcsr_sweep): same results, bit for bit, in every encoding -------------------

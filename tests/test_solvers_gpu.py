@@ -311,6 +311,34 @@ def test_galerkin_rebuild_numeric_only():
     assert abs(got - want).max() <= 1e-13 * abs(want).max()
 
 
+def test_mass_matrix_coarsening_on_the_device():
+    """M_coarse = Q^T M Q (Multigrid.py:273-275, :763) for every level by the hierarchy's SpGEMM plans: equal
+    to SciPy's sparse product bit for bit; a numeric refresh after the mass values changed."""
+    from learnmultigrid_amd.hierarchy import Hierarchy
+    from learnmultigrid_amd.assembly import P1Mesh2D
+    m, levels = 64, 3
+    A, _ = P.poisson_2d_structured(m)
+    mesh = P1Mesh2D.structured(m, "cuda:0") if hasattr(P1Mesh2D, "structured") else None
+    rng = np.random.default_rng(3)
+    # a mass-like matrix on A's pattern (positive, symmetric pattern)
+    M = sp.csr_matrix((rng.random(A.nnz) + 0.1, A.indices, A.indptr), shape=A.shape)
+    hier = P.geometric_hierarchy_2d(m + 1, levels)
+    H = Hierarchy(A, hier, "cuda:0", mass=M)
+    want = M
+    for l, Pm in enumerate(hier):
+        want = sp.csr_matrix(sp.csr_matrix(Pm.T @ want) @ Pm)
+        got = H.levels[l + 1].M.to_scipy()
+        assert got.shape == want.shape and abs(got - want).max() == 0.0, l
+    M2 = sp.csr_matrix((rng.random(A.nnz) + 0.1, A.indices, A.indptr), shape=A.shape)
+    H.rebuild_mass_numeric(torch.from_numpy(M2.data.copy()).to("cuda:0"))
+    want = M2
+    for l, Pm in enumerate(hier):
+        want = sp.csr_matrix(sp.csr_matrix(Pm.T @ want) @ Pm)
+        assert abs(H.levels[l + 1].M.to_scipy() - want).max() == 0.0
+    with pytest.raises(ValueError):
+        Hierarchy(A, hier, "cuda:0", mass=M[:100, :100])
+
+
 def test_full_size_properties_4097():
     """cfg#4 size (4097^2, 6 levels), size-independent properties instead of an oracle run:
     monotone residual history with a multigrid-like factor, linearity in the rhs, and

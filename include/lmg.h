@@ -48,8 +48,11 @@ int lmg_device_count(void);
 
 /* Runtime tuning knobs (kernel variant selection; used by bench.py for A/B runs).
  *   key "pcsr_ju"       : row entries per step of the packed sweeps (0 = auto, 1, 3, 5).
- *   key "sweep_variant" : tile geometry of the sweep kernels, 0..23 (0 = default: chosen
- *                         per launch from the average row length).                     */
+ *   key "sweep_variant" : tile geometry of the plain-CSR sweep kernels, 0..6 (0 = default: chosen
+ *                         per launch from the average row length).
+ *   keys "rpat_variant", "rpat_nt_rows", "stencil_nt_rows", "stencil_wgs_per_cu", "fused_seg_lines",
+ *        "fused_pf", "gs_single_max": geometry / cache-policy knobs of the twin kernels (parity tests force
+ *        the instantiations a launcher would only pick on very large operators).       */
 int lmg_tune_set(const char *key, int value);
 int lmg_tune_get(const char *key);
 

@@ -75,7 +75,7 @@ SQUARE = ["poisson1d_1025", "poisson2d_65", "poisson2d_513", "ragged_1000", "rag
 ALL = SQUARE + ["prolong_65", "restrict_65", "l2like_restrict"]
 
 
-@pytest.fixture(params=list(range(24)), ids=lambda r: "variant%d" % r)
+@pytest.fixture(params=list(range(7)), ids=lambda r: "variant%d" % r)
 def rpt(request):
     ops.tune_set("sweep_variant", request.param)
     yield request.param

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--size", type=int, default=4096)
-    ap.add_argument("--variants", default="1,2,3,4,5,6,7,8,10,11,12")
+    ap.add_argument("--variants", default="1,2,3,4,5,6")
     ap.add_argument("--reps", type=int, default=15)
     ap.add_argument("--inner", type=int, default=10)
     ap.add_argument("--matrix", default="A0")

@@ -41,6 +41,7 @@ PMC_TRAFFIC = {
     (4096, "csr"): (1485261824, "profiles/r01_csr_sweepmode_pmc_fetch_write.txt"),
     (4096, "pcsr"): (672639665, "profiles/r01_packed_sweep_pmc_fetch_write.txt"),
     (4096, "rpat"): (451701453, "profiles/r01_rpat_sweep_pmc_fetch_write.txt"),
+    (4096, "stencil"): (420151166, "profiles/r02_stencil_sweep_pmc_fetch_write.txt"),
 }
 
 
@@ -191,6 +192,8 @@ def main():
     backend = os.environ.get("LMG_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    torch.zeros(1, device=dev)                     # HIP context of the process: not part of the hierarchy setup
+    torch.cuda.synchronize()
     force_dist = os.environ.get("LMG_FORCE_DIST") == "1"     # drive the partitioned path on 1 GPU
     if world > 1 or force_dist:
         if "MASTER_ADDR" not in os.environ:

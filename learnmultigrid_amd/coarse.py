@@ -319,8 +319,7 @@ class BandedBlockSolver:
         o.dense_gemv_blockdiag(self.blocks, bI, self.y)           # y_I = A_II^-1 b_I
         o.csr_spmv(self.A_SI, self.y, bS, -1.0, 1.0)              # g_S = b_S - A_SI y_I   (in place)
         o.dense_gemv(self.Sinv, bS, xS)                           # x_S = S^-1 g_S
-        o.copy(bI, self.t)
-        o.csr_spmv(self.A_IS, xS, self.t, -1.0, 1.0)              # t_I = b_I - A_IS x_S
+        o.csr_residual_norm2(self.A_IS, xS, bI, self.t, None, None)      # t_I = b_I - A_IS x_S (one launch)
         o.dense_gemv_blockdiag(self.blocks, self.t, xI)           # x_I = A_II^-1 t_I
         o.scatter(self.perm, self.xp, x)
 

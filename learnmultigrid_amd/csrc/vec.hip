@@ -133,6 +133,39 @@ __global__ void __launch_bounds__(kBlock) dense_gemv_kernel(int64_t n, int64_t m
     }
 }
 
+// The same product with one WORKGROUP (4 waves) per row: a few thousand long rows (the Schur-complement
+// inverse of the banded coarse solver, 2967 x 2967) give one wave per row too little to keep 256 CUs busy
+// (26 us for 70 MB; 4 waves per row: see DESIGN.md).  The four partial sums are added in wave order, so the
+// result does not depend on the launch geometry of other rows -- but it differs in rounding from the
+// one-wave kernel, which is why the choice between the two only depends on (n, m).
+__global__ void __launch_bounds__(kBlock) dense_gemv_wgrow_kernel(int64_t n, int64_t m, const double *M,
+                                                                  const double *x, double *y)
+{
+    __shared__ double s_part[kBlock / LMG_WAVE];
+    const int t = threadIdx.x, lane = t & (LMG_WAVE - 1), w = t / LMG_WAVE;
+    for (int64_t row = blockIdx.x; row < n; row += gridDim.x) {
+        const double2 *M2 = reinterpret_cast<const double2 *>(M + row * m);
+        const double2 *x2 = reinterpret_cast<const double2 *>(x);
+        double s = 0.0;
+        for (int64_t j = t; j < m / 2; j += kBlock) {
+            const double2 mv = M2[j], xv = x2[j];
+            s += mv.x * xv.x;
+            s += mv.y * xv.y;
+        }
+        if ((m & 1) && t == 0) s += M[row * m + m - 1] * x[m - 1];
+        s = lmg_wave_sum(s);
+        if (lane == 0) s_part[w] = s;
+        __syncthreads();
+        if (t == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int q = 0; q < kBlock / LMG_WAVE; ++q) tot += s_part[q];
+            y[row] = tot;
+        }
+        __syncthreads();
+    }
+}
+
 // Batched GEMV on windows of a vector: for block k and row r
 //     y[k*ys + r] = (z ? z[k*zs + r] : 0) + alpha * sum_c M[k][r][c] * x[k*xs + c]
 // (M: nb dense rows x cols blocks, row-major, one after the other).  One wave per row, like
@@ -468,6 +501,12 @@ int lmg_dense_gemv(int64_t n, int64_t m, const double *M, const double *x, doubl
     if (n < 0 || m < 0 || (n > 0 && !y) || (n > 0 && m > 0 && (!M || !x))) return LMG_ERR_ARG;
     if (n == 0) return LMG_OK;
     if (!lmg_aligned16(M) || !lmg_aligned16(x)) return LMG_ERR_ALIGN;
+    if (n <= 8192 && m >= 1024) {
+        hipLaunchKernelGGL(dense_gemv_wgrow_kernel, dim3((unsigned)(n < 4096 ? n : 4096)), dim3(kBlock), 0,
+                           lmg_stream(stream), n, m, M, x, y);
+        LMG_CHECK_LAUNCH();
+        return LMG_OK;
+    }
     hipLaunchKernelGGL(dense_gemv_kernel, dim3(grid_for(n, kBlock / LMG_WAVE)), dim3(kBlock), 0,
                        lmg_stream(stream), n, m, M, x, y, (int64_t)0);
     LMG_CHECK_LAUNCH();

@@ -404,7 +404,7 @@ def test_vector_ops():
     assert np.array_equal(tgt.cpu().numpy(), w)
 
 
-@pytest.mark.parametrize("n,m", [(1, 1), (7, 5), (300, 300), (513, 513), (1000, 1024)])
+@pytest.mark.parametrize("n,m", [(1, 1), (7, 5), (300, 300), (513, 513), (1000, 1024), (2967, 2967), (3, 4097), (9000, 1030)])
 def test_dense_gemv(n, m):
     rng = np.random.default_rng(11)
     M, x = rng.standard_normal((n, m)), rng.standard_normal(m)

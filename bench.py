@@ -42,6 +42,10 @@ PMC_TRAFFIC = {
     (4096, "pcsr"): (672639665, "profiles/r01_packed_sweep_pmc_fetch_write.txt"),
     (4096, "rpat"): (451701453, "profiles/r01_rpat_sweep_pmc_fetch_write.txt"),
     (4096, "stencil"): (420151166, "profiles/r02_stencil_sweep_pmc_fetch_write.txt"),
+    # the fused passes re-read halo lines / columns of neighbouring strips: 3 sweeps 2 x 192 406 KB + 132 831 KB,
+    # 3 sweeps + residual 2 x 216 479 KB + 265 080 KB (compulsory: 419.6 / 553.9 MB)
+    (4096, "fused"): (530065964, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
+    (4096, "fused_resid"): (714790521, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
 }
 
 
@@ -408,7 +412,11 @@ def main():
                 tf = ev0.elapsed_time(ev1) * 1e-3 / 20
                 moved = nrow * (1 + 24 + (8 if r_ is not None else 0))
                 napply = k_ + (1 if r_ is not None else 0)
+                pm = PMC_TRAFFIC.get((args.size, "fused_resid" if r_ is not None else "fused")) if (
+                    args.problem == "poisson" and k_ == 3) else None
                 fused[lab] = {"kernel": "stencil_fused_kernel", "avg_launch_ms": tf * 1e3,
+                              "traffic": None if pm is None else pm[0],
+                              "traffic_source": None if pm is None else "%s (separate rocprofv3 --pmc passes, not this run)" % pm[1],
                               "operator_applications_per_launch": napply,
                               "compulsory_bytes_per_launch": moved, "GBps": moved / tf / 1e9,
                               "frac": moved / tf / 1e9 / HBM_PEAK_GBS,

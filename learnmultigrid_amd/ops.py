@@ -529,7 +529,9 @@ class StencilTwin:
         # wavefront Gauss-Seidel (lmg_stencil_gs_sweep) needs a supported slot set and no coupling across the
         # ends of a line: rows in column 0 must not reach column - 1, rows in column W - 1 not column + 1
         self._gs_work = None
-        self.gs_ok = bool(_lib.lib().lmg_stencil_gs_supported(self.umask)) and self.n >= 2
+        # (1-D chains are one lane of the wavefront kernel; the one-wave chain executor of gs.hip, x in LDS, is
+        # faster there: 0.29 vs 0.5 us per row)
+        self.gs_ok = bool(_lib.lib().lmg_stencil_gs_supported(self.umask)) and self.n >= 2 and bool(self.umask & 0x1C7)
         if self.gs_ok:
             mk = self.st_mask
             first = mk[R.pid[0::W].long()]

@@ -168,7 +168,7 @@ def _seven_point(m):
     return K.as_csr(sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsr())
 
 
-@pytest.mark.parametrize("name", ["poisson2d_129", "poisson2d_300", "galerkin_9pt", "galerkin_9pt_257", "poisson1d",
+@pytest.mark.parametrize("name", ["poisson2d_129", "poisson2d_300", "galerkin_9pt", "galerkin_9pt_257",
                                   "with_empty_and_diagless_rows", "seven_point_150"])
 def test_wavefront_gauss_seidel_bit_exact(name):
     """Exact forward Gauss-Seidel as a pipelined wavefront (gs_wave.hip: a wave per 64 grid lines, bands
@@ -211,6 +211,12 @@ def test_wavefront_gauss_seidel_bit_exact(name):
         assert torch.equal(x2, x)
     finally:
         ops.set_wavefront_gs_enabled(True)
+
+
+def test_wavefront_gauss_seidel_leaves_chains_to_the_chain_executor():
+    dA = ops.DeviceCSR.from_scipy(rpat_case("poisson1d"), DEV)
+    dA.pack()
+    assert dA.stencil is not None and not dA.stencil.gs_ok and not ops.stencil_gs_available(dA)
 
 
 def test_wavefront_gauss_seidel_refuses_coupling_across_line_ends():

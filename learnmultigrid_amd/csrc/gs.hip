@@ -272,12 +272,9 @@ int lmg_csr_gs_schedule(const int32_t *rp, const int32_t *ci, const double *va, 
         const int n = (int)total_rows;
         const size_t lds = (size_t)n * sizeof(double);
         if (lds <= 144 * 1024) {
-            static bool attr_done = false;
-            if (!attr_done) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gs_chain_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-                attr_done = true;
-            }
+            // (set on every call: the attribute is per device, and a process may drive several)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(gs_chain_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             hipLaunchKernelGGL(gs_chain_kernel<true>, dim3(1), dim3(64), lds, st, rp, ci, va, x, b, d_set_rows, n,
                                n, sweeps);
         } else {

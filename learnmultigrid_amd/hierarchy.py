@@ -67,8 +67,16 @@ class Hierarchy:
         # `ops_mod` exists for the CPU-only host-logic tests (a test shim stands in for the
         # HIP kernels); the product always runs with learnmultigrid_amd.ops.
         self.ops = ops if ops_mod is None else ops_mod
-        ops_ = self.ops
         self.device = torch.device(device)
+        # every kernel wrapper launches on the CURRENT device's stream: build on the device that holds the data
+        if self.device.type == "cuda":
+            with torch.cuda.device(self.device):
+                self._build(A, transfers, coarse_refine, verbose, use_packed, coarse_solver, spgemm_record, mass)
+        else:
+            self._build(A, transfers, coarse_refine, verbose, use_packed, coarse_solver, spgemm_record, mass)
+
+    def _build(self, A, transfers, coarse_refine, verbose, use_packed, coarse_solver, spgemm_record, mass):
+        ops_ = self.ops
         self.coarse_refine = int(coarse_refine)
         self.coarse_strategy = coarse_solver
         self.verbose = verbose
@@ -144,6 +152,9 @@ class Hierarchy:
     def rebuild_numeric(self, new_vals):
         """Galerkin rebuild after the VALUES of the fine matrix changed (same pattern):
         numeric SpGEMM passes only, then the coarse factorisation (config #5)."""
+        if self.device.type == "cuda" and torch.cuda.current_device() != self.device.index and self.device.index is not None:
+            with torch.cuda.device(self.device):
+                return self.rebuild_numeric(new_vals)
         A0 = self.levels[0].A
         if new_vals.numel() != A0.nnz:
             raise ValueError("rebuild_numeric needs the same sparsity pattern")

@@ -14,7 +14,7 @@ import torch
 
 from .. import ops
 from ..ops import F64
-from .Solver import IterativeSolver
+from .Solver import IterativeSolver, on_device
 
 
 class CG(IterativeSolver):
@@ -24,6 +24,7 @@ class CG(IterativeSolver):
         self._log("Selected CG")
         self.label = "CG"
 
+    @on_device
     def solve(self, max_iterations=1000, error=1e-08, initial_guess=None, *, preconditioner=None,
               precond_steps=2, precond_omega=0.8):
         A = self._device_matrix()

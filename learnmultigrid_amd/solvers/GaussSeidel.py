@@ -10,7 +10,7 @@ import torch
 
 from .. import ops
 from ..ops import F64
-from .Solver import IterativeSolver
+from .Solver import IterativeSolver, on_device
 
 
 class GaussSeidel(IterativeSolver):
@@ -20,6 +20,7 @@ class GaussSeidel(IterativeSolver):
         self._log("Selected Gauss-Seidel")
         self.label = "Gauss-Seidel"
 
+    @on_device
     def solve(self, max_iterations=1000, error=1e-12, initial_guess=None, *, gs_mode="lexicographic"):
         A = self._device_matrix()
         n = self.dim

@@ -10,7 +10,7 @@ import torch
 
 from .. import ops
 from ..ops import F64
-from .Solver import IterativeSolver
+from .Solver import IterativeSolver, on_device
 
 
 class Jacobi(IterativeSolver):
@@ -20,6 +20,7 @@ class Jacobi(IterativeSolver):
         self._log("Selected Jacobi")
         self.label = "Jacobi"
 
+    @on_device
     def solve(self, max_iterations=1000, error=1e-12, initial_guess=None, *, omega=1.0):
         A = self._device_matrix()
         n = self.dim

@@ -29,7 +29,7 @@ import torch
 
 from .. import ops, problems
 from ..hierarchy import Hierarchy
-from .Solver import IterativeSolver
+from .Solver import IterativeSolver, on_device
 
 _SMOOTHERS = ("GaussSeidel", "Jacobi", "CG")          # Multigrid.py:149-155
 
@@ -93,6 +93,7 @@ class Multigrid(IterativeSolver):
         return smoother
 
     # -- Multigrid.solve (Multigrid.py:36-75) ---------------------------------------------------
+    @on_device
     def solve(self, levels=2, smoother="Jacobi", smooth_steps=1, max_iterations=100, error=1e-08,
               initial_guess=None, cycle="V", first_call=False, *, omega=1.0,
               smoother_semantics="as_shipped", gs_mode="lexicographic", coarse_refine=1,
@@ -149,6 +150,7 @@ class Multigrid(IterativeSolver):
         self.level_dims = H.sizes
 
     # -- Multigrid.v_cycle (Multigrid.py:77) ------------------------------------------------------
+    @on_device
     def v_cycle(self, A, u0, rhs, smoother, smooth_steps, error, levels, first_call=False, *,
                 omega=1.0, smoother_semantics="as_shipped", gs_mode="lexicographic",
                 coarse_refine=1):

@@ -1,12 +1,28 @@
 """Base solver API -- mirrors learn_multigrid/solvers/Solver.py:8-84 of the reference
 (same constructor, getters/setters, attributes and shapes) with the state living on an
 MI355X.  Host arrays handed back by getters are fresh NumPy arrays of shape (n, 1)."""
+import functools
+
 import numpy as np
 import scipy.sparse as sp
 import torch
 
 from .. import _lib, ops
 from ..ops import DeviceCSR, F64
+
+
+def on_device(method):
+    """Run a solver method with the solver's GPU as the current device: the kernel wrappers launch on the
+    CURRENT device's current stream, which must be the device that holds the tensors (Solver(..., device="cuda:1")
+    while cuda:0 is current)."""
+    @functools.wraps(method)
+    def wrapper(self, *args, **kw):
+        dev = getattr(self, "_device", None)
+        if dev is not None and dev.type == "cuda":
+            with torch.cuda.device(dev):
+                return method(self, *args, **kw)
+        return method(self, *args, **kw)
+    return wrapper
 
 
 def default_device():

@@ -298,6 +298,22 @@ class DistributedVCycle:
             for name in ("x", "b", "r", "tmp"):
                 setattr(d, name, torch.zeros(d.n_tot, dtype=F64, device=self.device))
             self.dl.append(d)
+        # ---- the exchange plans of all ranks must pair up: a send without its receive would hang in RCCL, so
+        # check it here, once, where a mismatch can still raise ---------------------------------------------
+        plan = [([(q, (idx[1] - idx[0]) if isinstance(idx, tuple) else int(idx.numel())) for q, idx, _b in d.send],
+                 [(q, cnt) for q, _off, cnt in d.recv]) for d in self.dl]
+        plans = [None] * self.world
+        dist.all_gather_object(plans, plan, group=group)
+        for l in range(self.n_dist):
+            for p in range(self.world):
+                for q, cnt in plans[p][l][0]:
+                    if (p, cnt) not in plans[q][l][1]:
+                        raise RuntimeError("halo plan of level %d: rank %d sends %d values to rank %d, which does not "
+                                           "expect them" % (l, p, cnt, q))
+                for q, cnt in plans[p][l][1]:
+                    if (p, cnt) not in plans[q][l][0]:
+                        raise RuntimeError("halo plan of level %d: rank %d expects %d values from rank %d, which does "
+                                           "not send them" % (l, p, cnt, q))
         # ---- local operators in the level layouts -------------------------------------------------
         for l in range(self.n_dist):
             d = self.dl[l]

@@ -29,11 +29,11 @@
 namespace {
 
 constexpr int kMaxPat = 64;
-constexpr int kPF = 6;                      // iterations (of two steps) between issuing a load and using its value
-constexpr int kPubDelay = 7;                // iterations between a result store and the progress that covers it: the
+constexpr int kPF = 5;                      // iterations (of two steps) between issuing a load and using its value
+constexpr int kPubDelay = 6;                // iterations between a result store and the progress that covers it: the
                                             // counted wait in front of the progress store also covers every LOAD issued
                                             // before that store, so it must not be shorter than the prefetch distance
-constexpr int kVmOpsPerIter = 9;            // vector-memory instructions per iteration: 6 loads, 2 result stores, progress
+constexpr int kVmOpsPerIter = 11;           // vector-memory instructions per iteration: 6 loads, 2 + 2 result stores, progress
 constexpr unsigned kMask5 = 0x0BAu, kMask9 = 0x1FFu, kMask7 = 0x1BBu, kMask1D = 0x038u;
 constexpr unsigned kOOB = 0xFFFFFFF0u;      // buffer offset beyond any num_records: the access is dropped / reads 0
 constexpr int kSc1 = 16;                    // buffer cache policy: sc1 (write-through / L1 bypass, agent scope)
@@ -247,18 +247,26 @@ __global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
             const double inB = dpp_lower(R);
             const double upB = lane == 0 ? second(cur.up, i - W + (SK - 1)) : inB;
             const double xb = step(x + 1, upB, second(cur.down, i + W + 1), second(cur.own, i + 1), second(cur.b, i), pb);
-            // ---- results: one 16-byte and one 8-byte write-through store, disabled ones out of range ----------
+            // ---- results: one 16-byte and one 8-byte store, disabled ones out of range.  Only the band's LAST line is
+            // read by another wave during this launch (the next band's lane 0), so only that lane stores write-through
+            // (sc1) -- 64 write-through lines per instruction cost 2 us per iteration (SQ_WAIT_ANY 70 %: every later
+            // load is counted behind them in vmcnt); all other lanes use plain stores, flushed at the kernel boundary.
             const bool actA = line_ok && x >= 0 && x < W && i < n, actB = line_ok && x + 1 >= 0 && x + 1 < W && i + 1 < n;
+            const bool shared = lane == last_lane;
             u4 v4;
             v4.x = (unsigned)__double2loint(xa);
             v4.y = (unsigned)__double2hiint(xa);
             v4.z = (unsigned)__double2loint(xb);
             v4.w = (unsigned)__double2hiint(xb);
-            __builtin_amdgcn_raw_buffer_store_b128(v4, rs_x, (actA && actB) ? (unsigned)i * 8u : kOOB, 0, kSc1);
+            const unsigned off16 = (actA && actB) ? (unsigned)i * 8u : kOOB;
             u2 v2;
             v2.x = actA ? v4.x : v4.z;
             v2.y = actA ? v4.y : v4.w;
-            __builtin_amdgcn_raw_buffer_store_b64(v2, rs_x, (actA != actB) ? (unsigned)(actA ? i : i + 1) * 8u : kOOB, 0, kSc1);
+            const unsigned off8 = (actA != actB) ? (unsigned)(actA ? i : i + 1) * 8u : kOOB;
+            __builtin_amdgcn_raw_buffer_store_b128(v4, rs_x, shared ? kOOB : off16, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(v2, rs_x, shared ? kOOB : off8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v4, rs_x, shared ? off16 : kOOB, 0, kSc1);
+            __builtin_amdgcn_raw_buffer_store_b64(v2, rs_x, shared ? off8 : kOOB, 0, kSc1);
             // ---- publish: the result stores of kPubDelay iterations ago have completed ----------------------
             {
                 constexpr int N = kVmOpsPerIter * (kPubDelay - 1);

@@ -95,25 +95,6 @@ __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
     const int t_end = min(a.tiles, t_begin + a.tiles_per_xcd);
     if (t_begin + slot >= t_end) return;
 
-    for (int i = t; i <= a.npat; i += kBlock) s_ptr[i] = a.pat_ptr[i];
-    for (int i = t; i < a.nent; i += kBlock) {
-        s_off[i] = a.pat_off[i];
-        s_val[i] = a.pat_val[i];
-    }
-    __syncthreads();
-    if (MODE == MODE_JACOBI) {
-        // diagonal of every pattern: its entries with offset 0, summed in storage order like
-        // the CSR sweep does per row; one division per pattern and workgroup instead of per row
-        for (int p = t; p < a.npat; p += kBlock) {
-            double d = 0.0;
-            for (int j = s_ptr[p]; j < s_ptr[p + 1]; ++j)
-                if (s_off[j] == 0) d += s_val[j];
-            s_diag[p] = d;
-            s_rdiag[p] = d != 0.0 ? 1.0 / d : 0.0;
-        }
-        __syncthreads();
-    }
-
     // Pattern ids and right-hand sides travel through registers two tiles ahead, in two register
     // sets (A, B) used alternately.  The loop body is straight-line on purpose: the loads of set A
     // are issued before the gathers of the tile that uses set B, so waiting for those gathers
@@ -221,6 +202,26 @@ __global__ void __launch_bounds__(kBlock) rpat_sweep_kernel(RArgs a)
     int tile = t_begin + slot;
     load_tile(tile, patA, bA);
     load_tile(tile + nslots, patB, bB);
+    // the pattern tables are staged while the first two tiles' ids and right-hand sides are in flight: on the small
+    // levels a workgroup has one tile, and table -> ids -> gathers would be three dependent trips to memory
+    for (int i = t; i <= a.npat; i += kBlock) s_ptr[i] = a.pat_ptr[i];
+    for (int i = t; i < a.nent; i += kBlock) {
+        s_off[i] = a.pat_off[i];
+        s_val[i] = a.pat_val[i];
+    }
+    __syncthreads();
+    if (MODE == MODE_JACOBI) {
+        // diagonal of every pattern: its entries with offset 0, summed in storage order like
+        // the CSR sweep does per row; one division per pattern and workgroup instead of per row
+        for (int p = t; p < a.npat; p += kBlock) {
+            double d = 0.0;
+            for (int j = s_ptr[p]; j < s_ptr[p + 1]; ++j)
+                if (s_off[j] == 0) d += s_val[j];
+            s_diag[p] = d;
+            s_rdiag[p] = d != 0.0 ? 1.0 / d : 0.0;
+        }
+        __syncthreads();
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the loop is entered with both sets complete
     while (tile + nslots < t_end) {
         process(tile, patA, bA);

@@ -104,7 +104,7 @@ struct Pair {
 // loads issued before the current one is processed (two register sets, 4-7 waves per SIMD) 0.0742 /
 // 0.0974 ms, residual 0.0845 / 0.1007 -- occupancy hides the latency better than registers do.
 template <int MODE, bool DIAG, bool NT>
-__global__ void __launch_bounds__(kBlock, 8) stencil_sweep_kernel(SArgs a)
+__global__ void __launch_bounds__(kBlock, DIAG ? 4 : 8) stencil_sweep_kernel(SArgs a)
 {
     constexpr int kP = 1;
     constexpr int kTileRows = 2 * kBlock * kP;
@@ -122,18 +122,6 @@ __global__ void __launch_bounds__(kBlock, 8) stencil_sweep_kernel(SArgs a)
         if (MODE == MODE_RESIDUAL && a.partial != nullptr && t == 0) a.partial[blockIdx.x] = 0.0;
         return;
     }
-
-    for (int i = t; i < a.npat * 9; i += kBlock) s_val[i] = a.st_val[i];
-    for (int i = t; i < a.npat; i += kBlock) {
-        const int m = a.st_mask[i];
-        s_mask[i] = m;
-        if (MODE == MODE_JACOBI) {
-            const double d = (m & 16) ? a.st_val[i * 9 + 4] : 0.0;
-            s_rdiag[i] = d != 0.0 ? 1.0 / d : 0.0;
-            if (d == 0.0) s_mask[i] = m | (1 << 16);          // bit 16: no usable diagonal -> copy x
-        }
-    }
-    __syncthreads();
 
     const int n = a.n;
     const int64_t W = a.W;
@@ -247,10 +235,27 @@ __global__ void __launch_bounds__(kBlock, 8) stencil_sweep_kernel(SArgs a)
         }
     };
 
+    // The first tile's rows are requested BEFORE the pattern table is staged: on the small levels of a cycle a
+    // workgroup has one tile, and table-then-rows would be two dependent trips to memory in a 5 us kernel.
     Pair<DIAG> PA[kP];
-    for (int tile = t_begin + slot; tile < t_end; tile += nslots) {
-        load_tile(tile, PA);
+    int tile = t_begin + slot;
+    load_tile(tile, PA);
+    for (int i = t; i < a.npat * 9; i += kBlock) s_val[i] = a.st_val[i];
+    for (int i = t; i < a.npat; i += kBlock) {
+        const int m = a.st_mask[i];
+        s_mask[i] = m;
+        if (MODE == MODE_JACOBI) {
+            const double d = (m & 16) ? a.st_val[i * 9 + 4] : 0.0;
+            s_rdiag[i] = d != 0.0 ? 1.0 / d : 0.0;
+            if (d == 0.0) s_mask[i] = m | (1 << 16);          // bit 16: no usable diagonal -> copy x
+        }
+    }
+    __syncthreads();
+    for (;;) {
         process(tile, PA);
+        tile += nslots;
+        if (tile >= t_end) break;
+        load_tile(tile, PA);
     }
     if (MODE == MODE_RESIDUAL && a.partial != nullptr) {
         // one partial per workgroup: the grid and the tile -> workgroup map are fixed for a given n,

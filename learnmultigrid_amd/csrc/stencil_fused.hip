@@ -88,18 +88,21 @@ __device__ __forceinline__ d2 load2(const double *__restrict__ v, int64_t i, int
 // counter (vmcnt): a load or store issued on only one side of a branch makes the compiler wait for the
 // smaller of the two counts after the join, i.e. for loads that were meant to stay in flight, and the wave
 // serialises on the memory latency once per line (measured: 0.157 -> see DESIGN.md).
+// Two later variants lost against this one IN THE CYCLE (same-box A/B of bench.py, cfg#4) although a stand-alone
+// timing loop liked them: (a) 32-bit buffer addressing with range-checked loads instead of the clamped 64-bit
+// addresses below -- cycle 0.987 vs 0.931 ms (pre-smoothing pass 214 vs 195 us, the 9-point level 100 / 81 vs
+// 79 / 63 us: the compiler turns the selects on the loaded halves into branches with their own waits);
+// (b) a prologue padded with dropped stores so that the compiler's wait at the loop top stays counted -- no gain.
+struct Line {
+    d2 x, b;
+    int praw;       // the two pattern ids as loaded (16 bits)
+    int ok;         // bit 0 / 1: element 0 / 1 is a row of the matrix; bit 2 / 3: the pair was clamped
+                    // up (i == -1) / down (i == n-1) and holds the wanted element in the other half
+};
+
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-struct Line {
-    u4 x, b;        // two doubles each, as loaded
-    int praw;       // the two pattern ids as loaded (16 bits; 0 where out of range)
-    int i;          // linear index of the first element (may lie outside [0, n))
-};
 constexpr unsigned kOOB = 0xFFFFFFF0u;        // buffer offset beyond any num_records: the access is dropped
-#ifndef LMG_FUSED_NT
-#define LMG_FUSED_NT 0
-#endif
-constexpr int kNtAux = LMG_FUSED_NT;          // cache policy of the streams without reuse (b, ids, outputs); 2 = nt: measured, no gain
 
 // window of one line for the two elements of a lane: [0] = x[. - 1], [1], [2] = the lane's own two, [3] = x[. + 2]
 template <bool SIDES>
@@ -163,6 +166,18 @@ __device__ __forceinline__ void apply_rows_hot(const double (&hv)[9], const d2 &
     }
 }
 
+// Probe builds only (tools/probe/fused_trace.hip): cycle counter of one wave at five points of every step.
+#ifdef LMG_FUSED_TRACE
+__device__ unsigned long long g_fused_trace[64 * 8];
+#define LMG_TRACE(slot)                                                                              \
+    do {                                                                                             \
+        if (item == LMG_FUSED_TRACE && lane == 0 && t - y_begin < 63)                                \
+            s_trace[(t - y_begin) * 8 + (slot)] = __builtin_readcyclecounter();                      \
+    } while (0)
+#else
+#define LMG_TRACE(slot)
+#endif
+
 constexpr int kUF = 6;          // steps per loop iteration = period of all register rings
 constexpr int kNBR = 6;         // depth of the b / id rings (>= S + 2)
 
@@ -176,6 +191,10 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
     __shared__ double s_val[kMaxPat * 9];
     __shared__ int s_mask[kMaxPat];
     __shared__ double s_rdiag[kMaxPat];
+#ifdef LMG_FUSED_TRACE
+    __shared__ unsigned long long s_trace[64 * 8];
+    for (int i = threadIdx.x; i < 64 * 8; i += kBlock) s_trace[i] = 0;
+#endif
 
     const int t_ = threadIdx.x;
     for (int i = t_; i < a.npat * 9; i += kBlock) s_val[i] = a.st_val[i];
@@ -196,7 +215,7 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
     const int64_t W = a.W;
     const int c0 = strip * U - H;                                // linear-index offset of lane 0's first element
     const int out_y0 = seg * a.seg_lines, out_y1 = min(a.lines, out_y0 + a.seg_lines);
-    const int y_begin = out_y0 - H;                              // first line loaded
+    const int y_begin = out_y0 - H, y_end = out_y1 + H;          // lines loaded: [y_begin, y_end)
     const int cidx = 2 * lane;                                   // window column of element 0
     // columns this lane may store (element 0 / 1): inside the strip's inner part and inside the line
     const bool colA = cidx >= H && cidx < kStripCols - H && c0 + cidx < W;
@@ -209,41 +228,39 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
     for (int s = 0; s < 9; ++s) hv[s] = a.hot_val[s];
     const double hrd = a.hot_rdiag;
 
-    // All addressing is 32-bit: i = y * W + (c0 + cidx) is the linear index of the lane's first element on
-    // line y -- negative or beyond n for lines / columns outside the matrix, where the buffer loads return zeros
-    // and the stores are dropped by the hardware's range check (probed on gfx950: a 16-byte access that
-    // straddles the END of the buffer still moves its valid half; one that starts at offset -8 moves nothing,
-    // hence the single special case i == -1).
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)(ZERO ? a.b : a.x), 0, (int)((unsigned)n * 8u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)a.b, 0, (int)((unsigned)n * 8u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void *)a.pid, 0, n, 0x00020000);
+    auto fetch = [&](int y, Line &L) {
+        const bool line_ok = y >= 0 && y < a.lines && y < y_end;             // wave-uniform, no branch on it
+        const int yc = min(max(y, 0), a.lines - 1);
+        const int64_t i = (int64_t)yc * W + c0 + cidx;
+        const bool okA = line_ok && i >= 0 && i < n, okB = line_ok && i + 1 >= 0 && i + 1 < n;
+        const int64_t j = min(max(i, (int64_t)0), (int64_t)n - 2);           // always a valid pair (n >= 2)
+        L.ok = (okA ? 1 : 0) | (okB ? 2 : 0) | (i == -1 ? 4 : 0) | (i == (int64_t)n - 1 ? 8 : 0);
+        unsigned short two;
+        __builtin_memcpy(&two, a.pid + j, 2);
+        L.praw = (int)two;
+        const d2u bb = *reinterpret_cast<const d2u *>(a.b + j);
+        L.b.x = bb.a;
+        L.b.y = bb.b;
+        if (!ZERO) {
+            const d2u xx = *reinterpret_cast<const d2u *>(a.x + j);
+            L.x.x = xx.a;
+            L.x.y = xx.b;
+        } else {
+            L.x.x = L.x.y = 0.0;
+        }
+    };
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)n * 8u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(RESID ? a.r : a.out, 0, (int)((unsigned)n * 8u), 0x00020000);
-    const int Wi = a.W, i00 = c0 + cidx;
-    auto fetch = [&](int y, Line &L) {
-        const int i = y * Wi + i00;
-        const bool before = i == -1;
-        const unsigned off = before ? 0u : (unsigned)i * 8u;
-        L.i = i;
-        L.b = __builtin_amdgcn_raw_buffer_load_b128(rs_b, off, 0, kNtAux);
-        if (!ZERO) L.x = __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0);
-        else L.x = u4{0u, 0u, 0u, 0u};
-        // (the 2-byte id load is range-checked as a whole: the pair that ends one byte past the buffer is read one
-        // id further in, like the pair that starts before it)
-        L.praw = (int)__builtin_amdgcn_raw_buffer_load_b16(rs_p, before ? 0u : (unsigned)(i == n - 1 ? i - 1 : i), 0, kNtAux);
-    };
-    // a lane stores where its column belongs to the strip's inner part and to the line (colA / colB) and the
-    // element is a row of the matrix (p2 bits 16 / 17); lines outside the segment's output range store nothing
     auto store2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, int p2, double va, double vb) {
         const bool yok = y >= out_y0 && y < out_y1;
-        const int i = y * Wi + i00;
+        const int64_t i = (int64_t)y * W + c0 + cidx;
         const bool stA = yok && colA && ((p2 >> 16) & 1), stB = yok && colB && ((p2 >> 17) & 1);
         u4 v4;
         v4.x = (unsigned)__double2loint(va);
         v4.y = (unsigned)__double2hiint(va);
         v4.z = (unsigned)__double2loint(vb);
         v4.w = (unsigned)__double2hiint(vb);
-        __builtin_amdgcn_raw_buffer_store_b128(v4, rs, (stA && stB) ? (unsigned)i * 8u : kOOB, 0, kNtAux);
+        __builtin_amdgcn_raw_buffer_store_b128(v4, rs, (stA && stB) ? (unsigned)i * 8u : kOOB, 0, 0);
         u2 v2;
         v2.x = stA ? v4.x : v4.z;
         v2.y = stA ? v4.y : v4.w;
@@ -272,28 +289,32 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
     for (int u = 0; u < PF; ++u) fetch(y_begin + u, pre[u]);
 
     const int t_last = out_y1 - 1 + S + (RESID ? 1 : 0);         // last step that still produces output
+#ifdef LMG_FUSED_TRACE
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ck0 = __builtin_readcyclecounter();
+#endif
     for (int tb = y_begin; tb <= t_last; tb += kUF) {
 #pragma unroll
         for (int u = 0; u < kUF; ++u) {
             const int t = tb + u;
+            LMG_TRACE(0);
             // ---- line t arrives ------------------------------------------------------------------
             const int q0 = u % kNBR;
             {
                 const Line &L = pre[u % PF];
-                const int i = L.i;
-                const bool before = i == -1;                               // (the pair was loaded one element further in)
+                const bool okA = L.ok & 1, okB = L.ok & 2, up = L.ok & 4, down = L.ok & 8;
                 d2 bv, xv;
-                bv.x = before ? 0.0 : __hiloint2double((int)L.b.y, (int)L.b.x);
-                bv.y = before ? __hiloint2double((int)L.b.y, (int)L.b.x) : __hiloint2double((int)L.b.w, (int)L.b.z);
-                xv.x = before ? 0.0 : __hiloint2double((int)L.x.y, (int)L.x.x);
-                xv.y = before ? __hiloint2double((int)L.x.y, (int)L.x.x) : __hiloint2double((int)L.x.w, (int)L.x.z);
-                const int praw = before ? (L.praw & 0xff) << 8 : (i == n - 1 ? (L.praw >> 8) & 0xff : L.praw);   // out of range: 0
-                const bool okA = (unsigned)i < (unsigned)n, okB = (unsigned)(i + 1) < (unsigned)n;
+                // (selects that only do something in the first / last lines of the matrix)
+                bv.x = okA ? (down ? L.b.y : L.b.x) : 0.0;
+                bv.y = okB ? (up ? L.b.x : L.b.y) : 0.0;
+                xv.x = okA ? (down ? L.x.y : L.x.x) : 0.0;
+                xv.y = okB ? (up ? L.x.x : L.x.y) : 0.0;
+                const int pa = down ? (L.praw >> 8) & 0xff : L.praw & 0xff, pb = up ? L.praw & 0xff : (L.praw >> 8) & 0xff;
                 Bq[q0] = bv;
                 X[0][u % 3] = xv;
-                Pq[q0] = praw | (okA ? 1 << 16 : 0) | (okB ? 1 << 17 : 0);
+                Pq[q0] = (okA ? pa : 0) | ((okB ? pb : 0) << 8) | ((L.ok & 3) << 16);
                 Hq[q0] = __all(Pq[q0] == hot2);
             }
+            LMG_TRACE(1);
             fetch(t + PF, pre[u % PF]);
             // ---- stages 1..S: iterate s on line t - s -----------------------------------------------
 #pragma unroll
@@ -333,8 +354,10 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
                     if (!((p2 >> 17) & 1)) nx.y = 0.0;
                 }
                 X[s][xc] = nx;
+                if (s == 1) LMG_TRACE(2);
                 if (s == S) store2(rs_out, t - S, p2, nx.x, nx.y);
             }
+            LMG_TRACE(3);
             // ---- residual of the final iterate on line t - S - 1 ---------------------------------------
             if (RESID) {
                 const int y = t - S - 1;
@@ -350,8 +373,16 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
                 }
                 store2(rs_r, y, p2, Bq[q].x - accA, Bq[q].y - accB);
             }
+            LMG_TRACE(4);
         }
     }
+#ifdef LMG_FUSED_TRACE
+    if (item == LMG_FUSED_TRACE && lane == 0) {
+        s_trace[63 * 8 + 6] = __builtin_amdgcn_s_memrealtime() - rt0;      // 100 MHz
+        s_trace[63 * 8 + 7] = __builtin_readcyclecounter() - ck0;
+        for (int i = 0; i < 64 * 8; ++i) g_fused_trace[i] = s_trace[i];
+    }
+#endif
 }
 
 int g_fused_seg_lines = 0;      // 0 = chosen per launch
@@ -430,7 +461,7 @@ int lmg_stencil_smooth(int64_t n, int32_t line_stride, const uint8_t *pid, int32
                        int sweeps, const double *x_in, const double *b, double omega, double *x_out, double *r_out,
                        void *stream)
 {
-    if (n < 0 || n >= (1ll << 29) - (1ll << 23) || npat < 1 || npat > kMaxPat || (union_mask & ~0x1FFu)) return LMG_ERR_ARG;   // 32-bit byte offsets
+    if (n < 0 || n >= (1ll << 29) - 4096 || npat < 1 || npat > kMaxPat || (union_mask & ~0x1FFu)) return LMG_ERR_ARG;   // 32-bit byte offsets
     if (sweeps < 1 || sweeps > 3) return LMG_ERR_ARG;
     if (n == 0) return LMG_OK;
     if (n < 2) return LMG_ERR_CAPACITY;

@@ -9,6 +9,7 @@ ap.add_argument("--size", type=int, default=4096)
 ap.add_argument("--seg", default="0")
 ap.add_argument("--pf", default="2,3")
 a = ap.parse_args()
+ops.FUSED_MIN_ROWS = 0          # time the fused pass at every size
 cases = []
 A, _ = P.poisson_2d_structured(a.size); cases.append(("5pt %d^2" % (a.size + 1), A))
 Pm = P.tensor_interpolator_2d(a.size + 1)

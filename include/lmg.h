@@ -190,6 +190,27 @@ int lmg_stencil_smooth(int64_t n, int32_t line_stride, const uint8_t *d_pid, int
                        int32_t hot_pattern, const double *h_hot_val, int sweeps, const double *d_x_in,
                        const double *d_b, double omega, double *d_x_out, double *d_r_out, void *stream);
 
+/* The same pass with the coarse-grid correction folded in (Multigrid.py:115 + :121 in one pass):
+ *     x_out = J^sweeps(x_in + P e_coarse)
+ * for a prolongation P whose row (y, x) -- y = row / line_stride, x = row % line_stride -- reads
+ * e_coarse only at  ((y >> 1) * coarse_stride + (x >> 1)) + {0, 1, coarse_stride, coarse_stride + 1}  (slots
+ * 0..3, ascending columns): the tensor-product interpolation between nested grids, stored as row
+ * patterns (d_p_pid: one uint8 id per row of P; d_p_val [p_npat][4] values by slot, d_p_mask [p_npat]
+ * slots present; rows on even lines must not use slots 2, 3).  x_in + P e is never written: the
+ * correction is formed when a line arrives, with the sums of lmg_rpat_sweep_grid(SPMV, alpha = 1, beta = 1)
+ * in the same order, so x_out has the bits of prolongation + separate sweeps.  h_hot_pairs (HOST, 2 ints,
+ * may be NULL): for even / odd lines the ids (even column | odd column << 8) of the usual pattern pair,
+ * with masks {0}, {0,1} / {0,2}, {0,1,2,3}, or -1; h_hot_pval (HOST, 9 doubles): their values in that
+ * order.  5- and 9-point union masks (lmg_stencil_smooth_prolong_supported). */
+int lmg_stencil_smooth_prolong_supported(uint32_t union_mask);
+int lmg_stencil_smooth_prolong(int64_t n, int32_t line_stride, const uint8_t *d_pid, int32_t npat,
+                               const double *d_st_val, const int32_t *d_st_mask, uint32_t union_mask,
+                               int32_t hot_pattern, const double *h_hot_val, int sweeps, const double *d_x_in,
+                               const double *d_b, double omega, double *d_x_out, int64_t n_coarse,
+                               int32_t coarse_stride, const double *d_e_coarse, const uint8_t *d_p_pid,
+                               int32_t p_npat, const double *d_p_val, const int32_t *d_p_mask,
+                               const int32_t *h_hot_pairs, const double *h_hot_pval, void *stream);
+
 /* ---- sliced-ELL ("SELL-64") sweeps: matrices with long rows ---------------------------
  * Third lossless twin.  Slice s = rows 64 s .. 64 s + 63, padded to its longest row
  * d_slice_len[s]; entry j of row r lives at d_slice_base[s] + 64 j + (r mod 64) of d_col

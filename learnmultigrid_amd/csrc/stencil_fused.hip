@@ -52,6 +52,23 @@ struct MArgs {
     int hot;                  // most frequent pattern with all union slots and a diagonal, or -1
     double hot_val[9];        // its values by slot (scalar registers in the kernel)
     double hot_rdiag;         // 1 / its diagonal
+    // PROL: x_in + P e_c is formed on the fly (the correction of Multigrid.py:115 fused into the post-smoothing pass)
+    const double *ec;         // coarse vector
+    int nc, Wc;               // its length and line stride: row (y, x) of P reads columns ((y >> 1) * Wc + (x >> 1)) + {0, 1, Wc, Wc + 1}
+    const unsigned char *ppid;    // pattern id of every row of P
+    const double *pp_val;     // [pp_npat][4] values by slot
+    const int *pp_mask;       // [pp_npat] slots present
+    int pp_npat;
+    int hotp[2];              // even / odd lines: ids (A | B << 8) of the frequent pair of an (even, odd) column pair, or -1
+    double hp[9];             // their values: even line A s0 | B s0 s1 || odd line A s0 s2 | B s0 s1 s2 s3
+};
+
+// strip geometry: columns left of the stored part / stored columns of a 128-column window
+template <int H, bool PROL> struct StripGeom {
+    // PROL: the window starts on an even column (lane l then owns coarse column c0 / 2 + l) and its last pair is
+    // never exact (lane 63 has no right-hand coarse neighbour), so the right margin is H + 2 or more
+    static constexpr int ML = PROL ? ((H + 1) & ~1) : H;
+    static constexpr int U = PROL ? ((kStripCols - ML - (H + 2)) & ~1) : kStripCols - 2 * H;
 };
 
 __device__ __forceinline__ double dpp_lower(double src)      // lane i <- lane i-1, lane 0 <- 0
@@ -95,6 +112,8 @@ __device__ __forceinline__ d2 load2(const double *__restrict__ v, int64_t i, int
 // (b) a prologue padded with dropped stores so that the compiler's wait at the loop top stays counted -- no gain.
 struct Line {
     d2 x, b;
+    double e;       // PROL: coarse line (y + 1) >> 1 at the lane's coarse column
+    int pp;         // PROL: the two pattern ids of P as loaded
     int praw;       // the two pattern ids as loaded (16 bits)
     int ok;         // bit 0 / 1: element 0 / 1 is a row of the matrix; bit 2 / 3: the pair was clamped
                     // up (i == -1) / down (i == n-1) and holds the wanted element in the other half
@@ -183,14 +202,17 @@ constexpr int kNBR = 6;         // depth of the b / id rings (>= S + 2)
 
 // UM: the union slot mask of the matrix, compile time (5-point, 9-point, 1-D chain: anything else runs
 // the separate sweeps) -- a run-time mask costs a scalar branch per slot, stage and line.
-template <int S, unsigned UM, bool RESID, bool ZERO, int PF>
+template <int S, unsigned UM, bool RESID, bool ZERO, int PF, bool PROL = false>
 __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
 {
+    static_assert(!PROL || (!RESID && !ZERO), "the correction is fused into post-smoothing passes only");
     static_assert(kUF % 3 == 0 && kUF % kNBR == 0 && kUF % PF == 0 && S + 2 <= kNBR, "ring periods");
     constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);      // halo in lines and columns
     __shared__ double s_val[kMaxPat * 9];
     __shared__ int s_mask[kMaxPat];
     __shared__ double s_rdiag[kMaxPat];
+    __shared__ double s_pv[PROL ? kMaxPat * 4 : 1];
+    __shared__ int s_pm[PROL ? kMaxPat : 1];
 #ifdef LMG_FUSED_TRACE
     __shared__ unsigned long long s_trace[64 * 8];
     for (int i = threadIdx.x; i < 64 * 8; i += kBlock) s_trace[i] = 0;
@@ -204,22 +226,28 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
         s_rdiag[i] = dg != 0.0 ? 1.0 / dg : 0.0;
         s_mask[i] = dg == 0.0 ? (m | (1 << 16)) : m;             // bit 16: no usable diagonal -> copy x
     }
+    if (PROL) {
+        for (int i = t_; i < a.pp_npat * 4; i += kBlock) s_pv[i] = a.pp_val[i];
+        for (int i = t_; i < a.pp_npat; i += kBlock) s_pm[i] = a.pp_mask[i];
+    }
     __syncthreads();
 
     const int lane = t_ & (LMG_WAVE - 1);
     const int item = (int)blockIdx.x * kWavesPerBlock + (t_ >> 6);
     if (item >= a.strips * a.segs) return;
     const int seg = item / a.strips, strip = item - seg * a.strips;
-    constexpr int U = kStripCols - 2 * H;                        // columns a strip stores
+    constexpr int U = StripGeom<H, PROL>::U, ML = StripGeom<H, PROL>::ML;   // columns a strip stores / its left margin
     const int n = a.n;
     const int64_t W = a.W;
-    const int c0 = strip * U - H;                                // linear-index offset of lane 0's first element
+    const int c0 = strip * U - ML;                               // linear-index offset of lane 0's first element
     const int out_y0 = seg * a.seg_lines, out_y1 = min(a.lines, out_y0 + a.seg_lines);
-    const int y_begin = out_y0 - H, y_end = out_y1 + H;          // lines loaded: [y_begin, y_end)
+    // lines loaded: [y_begin, y_end); PROL starts on an even line, so that the parity of a step is a compile-time
+    // property of its place in the unrolled block
+    const int y_begin = out_y0 - H - (PROL ? ((out_y0 - H) & 1) : 0), y_end = out_y1 + H;
     const int cidx = 2 * lane;                                   // window column of element 0
     // columns this lane may store (element 0 / 1): inside the strip's inner part and inside the line
-    const bool colA = cidx >= H && cidx < kStripCols - H && c0 + cidx < W;
-    const bool colB = cidx + 1 >= H && cidx + 1 < kStripCols - H && c0 + cidx + 1 < W;
+    const bool colA = cidx >= ML && cidx < ML + U && c0 + cidx < W;
+    const bool colB = cidx + 1 >= ML && cidx + 1 < ML + U && c0 + cidx + 1 < W;
     const double omega = a.omega;
     // hot pattern: id on both elements + both marked as rows; -1 (no hot pattern) never matches
     const int hot2 = a.hot >= 0 ? (a.hot | (a.hot << 8) | (3 << 16)) : -1;
@@ -227,6 +255,12 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
 #pragma unroll
     for (int s = 0; s < 9; ++s) hv[s] = a.hot_val[s];
     const double hrd = a.hot_rdiag;
+    double hp[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) hp[s] = PROL ? a.hp[s] : 0.0;
+    const int hotq_even = (PROL && a.hotp[0] >= 0) ? (a.hotp[0] | (3 << 16)) : -1;
+    const int hotq_odd = (PROL && a.hotp[1] >= 0) ? (a.hotp[1] | (3 << 16)) : -1;
+    double e_prev = 0.0;                                          // PROL: the coarse line the previous (even) line brought
 
     auto fetch = [&](int y, Line &L) {
         const bool line_ok = y >= 0 && y < a.lines && y < y_end;             // wave-uniform, no branch on it
@@ -247,6 +281,18 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
             L.x.y = xx.b;
         } else {
             L.x.x = L.x.y = 0.0;
+        }
+        if (PROL) {
+            unsigned short twop;
+            __builtin_memcpy(&twop, a.ppid + j, 2);
+            L.pp = (int)twop;
+            // every line brings ONE coarse line, (y + 1) >> 1: its own for an even y, the one below for an odd y
+            // (whose upper one came with line y - 1); clamped, like everything else, where nothing is there
+            const int64_t jc = (int64_t)((yc + 1) >> 1) * a.Wc + (c0 >> 1) + lane;
+            L.e = a.ec[min(max(jc, (int64_t)0), (int64_t)a.nc - 1)];
+        } else {
+            L.pp = 0;
+            L.e = 0.0;
         }
     };
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)n * 8u), 0x00020000);
@@ -309,6 +355,41 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
                 xv.x = okA ? (down ? L.x.y : L.x.x) : 0.0;
                 xv.y = okB ? (up ? L.x.x : L.x.y) : 0.0;
                 const int pa = down ? (L.praw >> 8) & 0xff : L.praw & 0xff, pb = up ? L.praw & 0xff : (L.praw >> 8) & 0xff;
+                if (PROL) {
+                    // x + P e_c for the two elements: row (y, x) of P reads e_c at ((y >> 1), (x >> 1)) + {0, 1} x {0, 1};
+                    // both elements of a lane share x >> 1 = c0 / 2 + lane.  Same sums in the same order as
+                    // lmg_rpat_sweep_grid(SPMV, alpha = 1, beta = 1): acc = 0; acc = acc + v * e per entry; x + acc.
+                    const bool odd = (u & 1) != 0;                        // y_begin is even: compile time after unrolling
+                    const int qa = down ? (L.pp >> 8) & 0xff : L.pp & 0xff, qb = up ? L.pp & 0xff : (L.pp >> 8) & 0xff;
+                    const int q2 = (okA ? qa : 0) | ((okB ? qb : 0) << 8) | ((L.ok & 3) << 16);
+                    const double en = L.e;
+                    const double e0 = odd ? e_prev : en, e1 = en;
+                    const double e0r = dpp_upper(e0), e1r = dpp_upper(e1);
+                    double accA, accB;
+                    if (__all(q2 == (odd ? hotq_odd : hotq_even))) {          // wave-uniform
+                        if (!odd) {
+                            accA = 0.0 + hp[0] * e0;
+                            accB = (0.0 + hp[1] * e0) + hp[2] * e0r;
+                        } else {
+                            accA = (0.0 + hp[3] * e0) + hp[4] * e1;
+                            accB = (((0.0 + hp[5] * e0) + hp[6] * e0r) + hp[7] * e1) + hp[8] * e1r;
+                        }
+                    } else {
+                        const int mA = s_pm[qa], mB = s_pm[qb];
+                        const double w[4] = {e0, e0r, e1, e1r};
+                        accA = 0.0;
+                        accB = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const double tA = accA + s_pv[qa * 4 + k] * w[k], tB = accB + s_pv[qb * 4 + k] * w[k];
+                            accA = ((mA >> k) & 1) ? tA : accA;
+                            accB = ((mB >> k) & 1) ? tB : accB;
+                        }
+                    }
+                    xv.x = okA ? xv.x + accA : 0.0;
+                    xv.y = okB ? xv.y + accB : 0.0;
+                    e_prev = en;
+                }
                 Bq[q0] = bv;
                 X[0][u % 3] = xv;
                 Pq[q0] = (okA ? pa : 0) | ((okB ? pb : 0) << 8) | ((L.ok & 3) << 16);
@@ -386,30 +467,37 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
 }
 
 int g_fused_seg_lines = 0;      // 0 = chosen per launch
+int g_fused_seg_min_lines = 0;  // fused_seg_lines applies to grids of this many lines (tuning one level of a cycle)
+int g_fused_seg_max_lines = 0x7fffffff;
 int g_fused_pf = 0;             // 0 = default
+int g_fused_want_waves = 5120;  // waves a launch aims at when it cuts the lines into segments ...
+int g_fused_floor_halos = 4;    // ... which are never shorter than this many halos (the redundant lines of a segment: 2 H)
 
-template <int S, unsigned UM, bool RESID, bool ZERO>
+template <int S, unsigned UM, bool RESID, bool ZERO, bool PROL = false>
 int launch4(MArgs a, hipStream_t st)
 {
     constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);
-    constexpr int U = kStripCols - 2 * H;
+    constexpr int U = StripGeom<H, PROL>::U;
     a.strips = (a.W + U - 1) / U;
-    // segments: enough waves to fill the chip (256 CUs x 16 waves), but no shorter than 4 H lines
-    int seg_lines = g_fused_seg_lines;
+    // Segments: about 1.25 x the waves the chip holds at once (256 CUs x 16), never shorter than g_fused_floor_halos
+    // halos.  Scanned in the cycle on one box (tools/ab_cycle.py, cfg#4): at 4097^2 the cycle takes 0.885 ms with
+    // 28-line segments (5 145 waves), 0.90 with 24 or 47, 0.91 - 0.95 with 32 - 42; at 2049^2 the floor (12 lines) is
+    // best, 0.91 vs 0.93 with 10 or 14 - 16 lines.
+    int seg_lines = (a.lines >= g_fused_seg_min_lines && a.lines <= g_fused_seg_max_lines) ? g_fused_seg_lines : 0;
     if (seg_lines <= 0) {
-        const int want_segs = (4096 + a.strips - 1) / a.strips;
+        const int want_segs = (g_fused_want_waves + a.strips - 1) / a.strips;
         seg_lines = (a.lines + want_segs - 1) / want_segs;
-        const int floor_lines = H > 0 ? 4 * H : 4;
+        const int floor_lines = H > 0 ? g_fused_floor_halos * H : 4;
         if (seg_lines < floor_lines) seg_lines = floor_lines;
     }
     a.seg_lines = seg_lines;
     a.segs = (a.lines + seg_lines - 1) / seg_lines;
     const int items = a.strips * a.segs;
     const int grid = (items + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (g_fused_pf == 3)
-        hipLaunchKernelGGL((stencil_fused_kernel<S, UM, RESID, ZERO, 3>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
+    if (g_fused_pf == 3 && !PROL)
+        hipLaunchKernelGGL((stencil_fused_kernel<S, UM, RESID, ZERO, 3, false>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
     else
-        hipLaunchKernelGGL((stencil_fused_kernel<S, UM, RESID, ZERO, 2>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
+        hipLaunchKernelGGL((stencil_fused_kernel<S, UM, RESID, ZERO, 2, PROL>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }
@@ -419,6 +507,16 @@ int launch2(MArgs a, bool resid, bool zero, hipStream_t st)
 {
     if (resid) return zero ? launch4<S, UM, true, true>(a, st) : launch4<S, UM, true, false>(a, st);
     return zero ? launch4<S, UM, false, true>(a, st) : launch4<S, UM, false, false>(a, st);
+}
+
+template <unsigned UM>
+int launch_prol(MArgs a, int sweeps, hipStream_t st)
+{
+    switch (sweeps) {
+    case 1: return launch4<1, UM, false, false, true>(a, st);
+    case 2: return launch4<2, UM, false, false, true>(a, st);
+    default: return launch4<3, UM, false, false, true>(a, st);
+    }
 }
 
 template <unsigned UM>
@@ -445,21 +543,44 @@ int lmg_fused_tune_set(const char *key, int v)
         g_fused_pf = v;
         return LMG_OK;
     }
+    if (strcmp(key, "fused_seg_min_lines") == 0) {
+        if (v < 0) return LMG_ERR_ARG;
+        g_fused_seg_min_lines = v;
+        return LMG_OK;
+    }
+    if (strcmp(key, "fused_seg_max_lines") == 0) {
+        if (v < 0) return LMG_ERR_ARG;
+        g_fused_seg_max_lines = v;
+        return LMG_OK;
+    }
+    if (strcmp(key, "fused_want_waves") == 0) {
+        if (v < 1) return LMG_ERR_ARG;
+        g_fused_want_waves = v;
+        return LMG_OK;
+    }
+    if (strcmp(key, "fused_floor_halos") == 0) {
+        if (v < 1) return LMG_ERR_ARG;
+        g_fused_floor_halos = v;
+        return LMG_OK;
+    }
     return LMG_ERR_ARG;
 }
 int lmg_fused_tune_get(const char *key)
 {
     if (strcmp(key, "fused_seg_lines") == 0) return g_fused_seg_lines;
     if (strcmp(key, "fused_pf") == 0) return g_fused_pf;
+    if (strcmp(key, "fused_seg_min_lines") == 0) return g_fused_seg_min_lines;
+    if (strcmp(key, "fused_seg_max_lines") == 0) return g_fused_seg_max_lines;
+    if (strcmp(key, "fused_want_waves") == 0) return g_fused_want_waves;
+    if (strcmp(key, "fused_floor_halos") == 0) return g_fused_floor_halos;
     return LMG_ERR_ARG;
 }
 
 extern "C" {
 
-int lmg_stencil_smooth(int64_t n, int32_t line_stride, const uint8_t *pid, int32_t npat, const double *st_val,
-                       const int32_t *st_mask, uint32_t union_mask, int32_t hot_pattern, const double *h_hot_val,
-                       int sweeps, const double *x_in, const double *b, double omega, double *x_out, double *r_out,
-                       void *stream)
+static int fill_args(MArgs &a, int64_t n, int32_t line_stride, const uint8_t *pid, int32_t npat, const double *st_val,
+                     const int32_t *st_mask, uint32_t union_mask, int32_t hot_pattern, const double *h_hot_val, int sweeps,
+                     const double *x_in, const double *b, double omega, double *x_out, double *r_out)
 {
     if (n < 0 || n >= (1ll << 29) - 4096 || npat < 1 || npat > kMaxPat || (union_mask & ~0x1FFu)) return LMG_ERR_ARG;   // 32-bit byte offsets
     if (sweeps < 1 || sweeps > 3) return LMG_ERR_ARG;
@@ -468,7 +589,6 @@ int lmg_stencil_smooth(int64_t n, int32_t line_stride, const uint8_t *pid, int32
     if (!pid || !st_val || !st_mask || !b || !x_out || x_in == x_out || r_out == x_out || (r_out && r_out == x_in))
         return LMG_ERR_ARG;
     if (line_stride < 3 || line_stride > n) return LMG_ERR_ARG;
-    MArgs a;
     a.n = (int)n;
     a.W = line_stride;
     a.lines = (int)((n + line_stride - 1) / line_stride);
@@ -491,6 +611,26 @@ int lmg_stencil_smooth(int64_t n, int32_t line_stride, const uint8_t *pid, int32
         for (int k = 0; k < 9; ++k) a.hot_val[k] = h_hot_val[k];
         a.hot_rdiag = 1.0 / h_hot_val[4];
     }
+    a.ec = nullptr;
+    a.nc = a.Wc = 0;
+    a.ppid = nullptr;
+    a.pp_val = nullptr;
+    a.pp_mask = nullptr;
+    a.pp_npat = 0;
+    a.hotp[0] = a.hotp[1] = -1;
+    for (int k = 0; k < 9; ++k) a.hp[k] = 0.0;
+    return 1;                                  // filled: launch
+}
+
+int lmg_stencil_smooth(int64_t n, int32_t line_stride, const uint8_t *pid, int32_t npat, const double *st_val,
+                       const int32_t *st_mask, uint32_t union_mask, int32_t hot_pattern, const double *h_hot_val,
+                       int sweeps, const double *x_in, const double *b, double omega, double *x_out, double *r_out,
+                       void *stream)
+{
+    MArgs a;
+    const int rc = fill_args(a, n, line_stride, pid, npat, st_val, st_mask, union_mask, hot_pattern, h_hot_val, sweeps, x_in, b,
+                             omega, x_out, r_out);
+    if (rc != 1) return rc;
     hipStream_t st = lmg_stream(stream);
     const bool resid = r_out != nullptr, zero = x_in == nullptr;
     switch (union_mask) {
@@ -501,9 +641,50 @@ int lmg_stencil_smooth(int64_t n, int32_t line_stride, const uint8_t *pid, int32
     }
 }
 
+int lmg_stencil_smooth_prolong(int64_t n, int32_t line_stride, const uint8_t *pid, int32_t npat, const double *st_val,
+                               const int32_t *st_mask, uint32_t union_mask, int32_t hot_pattern, const double *h_hot_val,
+                               int sweeps, const double *x_in, const double *b, double omega, double *x_out,
+                               int64_t n_coarse, int32_t coarse_stride, const double *e_coarse, const uint8_t *p_pid,
+                               int32_t p_npat, const double *p_val, const int32_t *p_mask, const int32_t *h_hot_pairs,
+                               const double *h_hot_pval, void *stream)
+{
+    if (!x_in || !e_coarse || !p_pid || !p_val || !p_mask || p_npat < 1 || p_npat > kMaxPat) return LMG_ERR_ARG;
+    if (n_coarse < 1 || n_coarse >= (1ll << 31) || coarse_stride < 1 || coarse_stride > n_coarse) return LMG_ERR_ARG;
+    if (e_coarse == x_out) return LMG_ERR_ARG;
+    // the 2 x 2 window of row (y, x) starts at ((y >> 1), (x >> 1)): the coarse line stride must cover the fine one
+    if ((int64_t)coarse_stride < ((int64_t)line_stride + 1) / 2) return LMG_ERR_ARG;
+    MArgs a;
+    const int rc = fill_args(a, n, line_stride, pid, npat, st_val, st_mask, union_mask, hot_pattern, h_hot_val, sweeps, x_in, b,
+                             omega, x_out, nullptr);
+    if (rc != 1) return rc;
+    a.ec = e_coarse;
+    a.nc = (int)n_coarse;
+    a.Wc = coarse_stride;
+    a.ppid = p_pid;
+    a.pp_val = p_val;
+    a.pp_mask = p_mask;
+    a.pp_npat = p_npat;
+    if (h_hot_pairs && h_hot_pval) {
+        a.hotp[0] = h_hot_pairs[0];
+        a.hotp[1] = h_hot_pairs[1];
+        for (int k = 0; k < 9; ++k) a.hp[k] = h_hot_pval[k];
+    }
+    hipStream_t st = lmg_stream(stream);
+    switch (union_mask) {
+    case kMask5: return launch_prol<kMask5>(a, sweeps, st);
+    case kMask9: return launch_prol<kMask9>(a, sweeps, st);
+    default: return LMG_ERR_CAPACITY;
+    }
+}
+
 int lmg_stencil_smooth_supported(uint32_t union_mask)
 {
     return union_mask == kMask5 || union_mask == kMask9 || union_mask == kMask1D;
+}
+
+int lmg_stencil_smooth_prolong_supported(uint32_t union_mask)
+{
+    return union_mask == kMask5 || union_mask == kMask9;
 }
 
 }  // extern "C"

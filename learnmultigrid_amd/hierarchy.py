@@ -237,18 +237,23 @@ class Hierarchy:
         avail = getattr(self.ops, "stencil_smooth_available", None)
         return (smoother == "Jacobi" and steps >= 1 and avail is not None and avail(self.levels[l].A))
 
-    def smooth_fused(self, l, steps, omega, x_is_zero=False, want_residual=False):
+    def smooth_fused(self, l, steps, omega, x_is_zero=False, want_residual=False, correction=None):
         """`steps` Jacobi sweeps on level l (and r = b - A x afterwards) as fused passes of at most
         FUSED_MAX_SWEEPS sweeps each (lmg_stencil_smooth): same bits as smooth() + the residual launch,
-        a third of the passes over the level's vectors."""
+        a third of the passes over the level's vectors.  correction = (P, e): the first pass starts from
+        x + P e (Multigrid.py:115 folded in; the caller has checked stencil_smooth_prolong_available)."""
         lev = self.levels[l]
         left = steps
         mx = self.ops.FUSED_MAX_SWEEPS
         while left > 0:
             k = min(left, mx)
             left -= k
-            self.ops.stencil_smooth(lev.A, None if x_is_zero else lev.x, lev.b, omega, k, lev.tmp,
-                                    lev.r if (want_residual and left == 0) else None)
+            if correction is not None:
+                self.ops.stencil_smooth(lev.A, lev.x, lev.b, omega, k, lev.tmp, None, prolong=correction)
+                correction = None
+            else:
+                self.ops.stencil_smooth(lev.A, None if x_is_zero else lev.x, lev.b, omega, k, lev.tmp,
+                                        lev.r if (want_residual and left == 0) else None)
             lev.x, lev.tmp = lev.tmp, lev.x
             x_is_zero = False
 
@@ -281,6 +286,10 @@ class Hierarchy:
             self.coarse_solve()                                               # :106
         else:
             self.cycle(smoother, steps, omega, gs_mode, l + 1, depth, x_is_zero=True)   # zeros, :103
+        pavail = getattr(self.ops, "stencil_smooth_prolong_available", None)
+        if fused and pavail is not None and pavail(lev.A, lev.P):
+            self.smooth_fused(l, steps, omega, correction=(lev.P, nxt.x))     # :115 + :121 in one pass
+            return
         self.ops.csr_spmv(lev.P, nxt.x, lev.x, 1.0, 1.0)                           # :115
         if fused:
             self.smooth_fused(l, steps, omega)                                # :121

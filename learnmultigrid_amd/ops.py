@@ -38,7 +38,7 @@ def _vec_ok(*ts):
 class DeviceCSR:
     """CSR matrix resident in HBM: int32 rowptr[n+1], int32 colidx[nnz], fp64 vals[nnz]."""
 
-    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz", "packed", "patterns", "sell", "stencil")
+    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz", "packed", "patterns", "sell", "stencil", "prolong")
 
     def __init__(self, rowptr, colidx, vals, shape):
         if rowptr.dtype != I32 or colidx.dtype != I32 or vals.dtype != F64:
@@ -52,6 +52,7 @@ class DeviceCSR:
         self.patterns = None         # RowPatterns twin (matrices with repeating rows), preferred
         self.sell = None             # SellCSR twin (long rows with all-distinct values)
         self.stencil = None          # StencilTwin view of `patterns` (3x3 grid stencils), preferred
+        self.prolong = None          # ProlongTwin view of `patterns` (2x2-window grid prolongations)
 
     def pack(self, patterns=None):
         """Build (once) the lossless twin the sweep kernels prefer; keeps the CSR arrays.
@@ -71,6 +72,7 @@ class DeviceCSR:
                     if self.patterns is not None:
                         break
             self.stencil = StencilTwin.from_patterns(self.patterns, self.shape) if _STENCIL_ENABLED else None
+            self.prolong = ProlongTwin.from_patterns(self.patterns, self.shape) if _STENCIL_ENABLED else None
         if patterns and self.patterns is not None:
             return self.patterns
         if self.sell is not None:
@@ -94,12 +96,14 @@ class DeviceCSR:
         self.patterns = None
         self.sell = None
         self.stencil = None
+        self.prolong = None
 
     def repack_values(self):
         """After the values changed in place: refresh the twins (cheaply if possible)."""
         if self.patterns is not None:
             self.patterns = RowPatterns.from_csr(self, self.patterns.grid_map)
             self.stencil = StencilTwin.from_patterns(self.patterns, self.shape) if _STENCIL_ENABLED else None
+            self.prolong = ProlongTwin.from_patterns(self.patterns, self.shape) if _STENCIL_ENABLED else None
             if self.patterns is None:
                 self.pack()
         if self.sell is not None:
@@ -543,6 +547,71 @@ class StencilTwin:
         return int(self.bytes_)
 
 
+class ProlongTwin:
+    """2x2-window view of the row-pattern twin of a PROLONGATION between nested grids for
+    lmg_stencil_smooth_prolong (see include/lmg.h): row (y, x) of the fine grid (line stride W) reads the coarse
+    vector only at ((y >> 1) * Wc + (x >> 1)) + {0, 1, Wc, Wc + 1} -- the tensor-product interpolation of
+    Multigrid.interpolator applied along both axes.  Derived on the host from the (already verified) pattern
+    table of a RowPatterns twin with the column-base map (W, Wc, 1, 1, 0); from_patterns returns None for
+    everything else (the correction then runs as its own lmg_rpat_sweep_grid launch)."""
+
+    __slots__ = ("n", "W", "nc", "Wc", "npat", "pid", "p_val", "p_mask", "_hot_pairs", "_hot_pval", "patterns")
+
+    @classmethod
+    def from_patterns(cls, R, shape):
+        if R is None or R.grid_map is None or R.npat > 64 or R.n < 2:
+            return None
+        W, Wc, ysh, xsh, xshl = R.grid_map
+        if (ysh, xsh, xshl) != (1, 1, 0) or Wc < 2 or W < 3 or 2 * Wc < W + 1 or shape[1] >= 2 ** 31:
+            return None
+        ptr = R.pat_ptr.cpu().numpy()
+        off = R.pat_off.cpu().numpy().astype(np.int64)[: R.nent]
+        val = R.pat_val.cpu().numpy()[: R.nent]
+        slot_of = {0: 0, 1: 1, Wc: 2, Wc + 1: 3}
+        p_val = np.zeros(R.npat * 4)
+        p_mask = np.zeros(R.npat, dtype=np.int32)
+        for p in range(R.npat):
+            o = off[ptr[p]:ptr[p + 1]]
+            if o.size > 4 or np.any(np.diff(o) <= 0) or any(int(v) not in slot_of for v in o):
+                return None
+            for j in range(ptr[p], ptr[p + 1]):
+                k = slot_of[int(off[j])]
+                p_mask[p] |= 1 << k
+                p_val[p * 4 + k] = val[j]
+        dev = R.pid.device
+        # which patterns occur where: counts by (line parity, column parity)
+        n = int(R.n)
+        rows = torch.arange(n, dtype=torch.int32, device=dev)
+        yp = torch.div(rows, W, rounding_mode="floor") & 1
+        xp = (rows - torch.div(rows, W, rounding_mode="floor") * W) & 1
+        key = (yp * 2 + xp).long() * R.npat + R.pid.long()
+        counts = torch.bincount(key, minlength=4 * R.npat).cpu().numpy().reshape(2, 2, R.npat)
+        del rows, yp, xp, key
+        if np.any((counts[0].sum(axis=0) > 0) & ((p_mask & 0xC) != 0)):
+            return None                        # a row on an even line reaching the coarse line below: not this shape
+        self = cls()
+        self.n, self.W, self.nc, self.Wc, self.npat = n, int(W), int(shape[1]), int(Wc), int(R.npat)
+        self.pid, self.patterns = R.pid, R
+        self.p_val = torch.from_numpy(p_val).to(dev)
+        self.p_mask = torch.from_numpy(p_mask).to(dev)
+        # the usual pattern pair of an (even, odd) column pair on even / odd lines, with exactly the slots of the
+        # tensor-product interpolation: their values travel in scalar registers
+        want = (((0x1, 0x3)), ((0x5, 0xF)))
+        pairs, pval = [], []
+        for yl in range(2):
+            ids = []
+            for xl in range(2):
+                cand = [p for p in range(R.npat) if p_mask[p] == want[yl][xl] and counts[yl][xl][p] > 0]
+                ids.append(max(cand, key=lambda p: counts[yl][xl][p]) if cand else -1)
+            pairs.append(-1 if min(ids) < 0 else ids[0] | (ids[1] << 8))
+            for xl in range(2):
+                m = want[yl][xl]
+                pval += [float(p_val[ids[xl] * 4 + k]) if ids[xl] >= 0 else 0.0 for k in range(4) if (m >> k) & 1]
+        self._hot_pairs = (ctypes.c_int32 * 2)(*pairs)
+        self._hot_pval = (ctypes.c_double * 9)(*pval)
+        return self
+
+
 _PACKED_ENABLED = True
 _PATTERNS_ENABLED = True
 _STENCIL_ENABLED = True
@@ -592,18 +661,50 @@ def set_fused_enabled(flag):
     _FUSED_ENABLED = bool(flag)
 
 
-def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None):
+def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None, prolong=None):
     """x_out = `sweeps` (1..3) weighted-Jacobi sweeps from x_in (None = zero iterate), r_out = b - A x_out
     (optional), in one pass (lmg_stencil_smooth); same bits as the separate csr_jacobi / vmul /
-    csr_residual_norm2 launches."""
+    csr_residual_norm2 launches.  prolong = (P, e): the sweeps start from x_in + P e (the correction of
+    Multigrid.py:115, never written: lmg_stencil_smooth_prolong; see stencil_smooth_prolong_available)."""
     _vec_ok(x_in, b, x_out, r_out)
     S = A.stencil
     if S is None:
         raise LmgError("stencil_smooth needs a grid-stencil matrix")
     hv = None if S._hot_val is None else ctypes.addressof(S._hot_val)
+    if prolong is not None:
+        P, e = prolong
+        T = P.prolong
+        _vec_ok(e)
+        if T is None or r_out is not None or x_in is None or T.n != S.n or T.W != S.W or e.numel() != T.nc:
+            raise LmgError("stencil_smooth: this prolongation cannot be fused into the pass")
+        check(_lib.lib().lmg_stencil_smooth_prolong(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask, S.hot,
+                                                    hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out), T.nc, T.Wc,
+                                                    _p(e), _p(T.pid), T.npat, _p(T.p_val), _p(T.p_mask),
+                                                    ctypes.addressof(T._hot_pairs), ctypes.addressof(T._hot_pval), _s()),
+              "lmg_stencil_smooth_prolong")
+        return
     check(_lib.lib().lmg_stencil_smooth(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask, S.hot, hv,
                                         int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out), _p(r_out), _s()),
           "lmg_stencil_smooth")
+
+
+_FUSED_PROLONG_ENABLED = True
+
+
+def set_fused_prolong_enabled(flag):
+    """Whether the coarse-grid correction may be folded into the fused post-smoothing pass (default) or runs as
+    its own launch (A/B runs and parity tests)."""
+    global _FUSED_PROLONG_ENABLED
+    _FUSED_PROLONG_ENABLED = bool(flag)
+
+
+def stencil_smooth_prolong_available(A, P):
+    """True when stencil_smooth can take `prolong=(P, e)`: A runs fused passes and P is a 2x2-window grid
+    prolongation onto A's grid."""
+    T = getattr(P, "prolong", None)
+    S = getattr(A, "stencil", None)
+    return bool(_FUSED_PROLONG_ENABLED and T is not None and stencil_smooth_available(A) and T.n == S.n and T.W == S.W
+                and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask))
 
 
 def _use_stencil(A, *vecs):

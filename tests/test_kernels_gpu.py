@@ -1080,6 +1080,74 @@ def test_fused_stencil_smoothing_equals_separate_sweeps(name, seg_lines, pf):
         ops.tune_set("fused_pf", 0)
 
 
+@pytest.mark.parametrize("m,kind", [(64, "5pt"), (150, "5pt"), (64, "9pt"), (129, "9pt")])
+@pytest.mark.parametrize("seg_lines", [0, 5, 1000])
+def test_fused_post_smoothing_with_the_correction_folded_in(m, kind, seg_lines):
+    """lmg_stencil_smooth_prolong: x_out = J^S(x + P e) in one pass, against the oracle's prolongation
+    (K.spmv alpha = beta = 1) followed by S separate Jacobi sweeps, bitwise; 5-point fine operators and
+    9-point Galerkin operators, tensor-product interpolation between (2m+1)^2 and (m+1)^2 nodes, strips /
+    segments that start on odd and even lines and columns."""
+    side = 2 * m + 1
+    if kind == "5pt":
+        A = K.as_csr(P.poisson_2d_structured(side - 1)[0])
+    else:
+        Af = P.poisson_2d_structured(2 * (side - 1))[0]
+        Pf = P.tensor_interpolator_2d(2 * (side - 1) + 1)
+        A = K.as_csr(sp.csr_matrix(Pf.T @ Af @ Pf))
+    Pm = K.as_csr(sp.csr_matrix(P.tensor_interpolator_2d(side)))
+    n, nc = A.shape[0], Pm.shape[1]
+    assert Pm.shape[0] == n and nc == (m + 1) ** 2
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    dA.pack()
+    dP = ops.DeviceCSR.from_scipy(Pm, DEV)
+    dP.pack()
+    T = dP.prolong
+    assert dA.stencil is not None and T is not None and (T.W, T.Wc, T.nc) == (side, m + 1, nc)
+    assert T._hot_pairs[0] >= 0 and T._hot_pairs[1] >= 0
+    rng = np.random.default_rng(5)
+    x0, b, e = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(nc)
+    try:
+        ops.tune_set("fused_seg_lines", seg_lines)
+        for omega in (0.8, 1.0):
+            want = K.spmv(Pm, e, x0.copy(), 1.0, 1.0)
+            for S in (1, 2, 3):
+                want = K.jacobi(A, want, b, omega)
+                out = torch.full((n,), np.nan, dtype=torch.float64, device=DEV)
+                ops.stencil_smooth(dA, dev(x0), dev(b), omega, S, out, None, prolong=(dP, dev(e)))
+                got = out.cpu().numpy()
+                assert not np.isnan(got).any(), (m, kind, S)
+                assert np.array_equal(got, want), (m, kind, omega, S, np.flatnonzero(got != want)[:8])
+        # without the frequent-pair shortcut (every line through the pattern table): same bits
+        hot = (T._hot_pairs[0], T._hot_pairs[1])
+        T._hot_pairs[0] = T._hot_pairs[1] = -1
+        out = torch.full((n,), np.nan, dtype=torch.float64, device=DEV)
+        ops.stencil_smooth(dA, dev(x0), dev(b), 1.0, 3, out, None, prolong=(dP, dev(e)))
+        T._hot_pairs[0], T._hot_pairs[1] = hot
+        assert np.array_equal(out.cpu().numpy(), want)
+    finally:
+        ops.tune_set("fused_seg_lines", 0)
+
+
+def test_prolong_twin_only_for_two_by_two_window_transfers():
+    """ProlongTwin.from_patterns accepts the tensor-product interpolation and nothing wider: an L2-type
+    transfer (3-point rows per axis) keeps its own launch."""
+    Pm = sp.csr_matrix(P.tensor_interpolator_2d(33))
+    dP = ops.DeviceCSR.from_scipy(Pm, DEV)
+    dP.pack()
+    assert dP.patterns is not None and dP.prolong is not None
+    l2 = P.pseudo_l2_interpolator_1d(33)
+    dQ = ops.DeviceCSR.from_scipy(sp.kron(l2, l2).tocsr(), DEV)
+    dQ.pack()
+    assert dQ.prolong is None
+    A = K.as_csr(P.poisson_2d_structured(32)[0])
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    dA.pack()
+    assert dA.prolong is None
+    with pytest.raises(ops.LmgError):
+        ops.stencil_smooth(dA, dev(np.zeros(33 * 33)), dev(np.zeros(33 * 33)), 0.8, 3,
+                           torch.empty(33 * 33, dtype=torch.float64, device=DEV), None, prolong=(dQ, dev(np.zeros(17 * 17))))
+
+
 def test_row_pattern_sweeps_full_size_4097_bit_exact_vs_oracle():
     """The instantiations the headline bench times -- stencil_sweep_kernel<JACOBI|RESIDUAL, NT = true> on
     the 16.8 M-row fine level of cfg#4 (and rpat_sweep_kernel<.., 5, 2, NT = true>, its fallback) --

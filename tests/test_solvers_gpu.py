@@ -391,6 +391,17 @@ def test_full_size_properties_4097():
         want0 = K.jacobi(Ac, want0, b, 0.8)
     ops.stencil_smooth(dA, None, db, 0.8, 2, out, None)
     assert np.array_equal(out.cpu().numpy(), want0)
+    # ... and the post-smoothing pass with the coarse-grid correction folded in (what the cycle above ran on the
+    # two finest levels): prolongation + 3 sweeps of the oracle, bitwise
+    lev0, lev1 = mg._hier.levels[0], mg._hier.levels[1]
+    assert ops.stencil_smooth_prolong_available(lev0.A, lev0.P) and ops.stencil_smooth_prolong_available(lev1.A, lev1.P)
+    Pm = K.as_csr(hier[0])
+    e = rng.standard_normal(Pm.shape[1])
+    want = K.spmv(Pm, e, x0.copy(), 1.0, 1.0)
+    for _ in range(3):
+        want = K.jacobi(Ac, want, b, 0.8)
+    ops.stencil_smooth(dA, dx, db, 0.8, 3, out, None, prolong=(lev0.P, torch.from_numpy(e).to("cuda:0")))
+    assert np.array_equal(out.cpu().numpy(), want)
 
 
 def test_g6_cg_matches_reference():

@@ -42,10 +42,12 @@ PMC_TRAFFIC = {
     (4096, "pcsr"): (672639665, "profiles/r01_packed_sweep_pmc_fetch_write.txt"),
     (4096, "rpat"): (451701453, "profiles/r01_rpat_sweep_pmc_fetch_write.txt"),
     (4096, "stencil"): (420151166, "profiles/r02_stencil_sweep_pmc_fetch_write.txt"),
-    # the fused passes re-read halo lines / columns of neighbouring strips: 3 sweeps 2 x 192 406 KB + 132 831 KB,
-    # 3 sweeps + residual 2 x 216 479 KB + 265 080 KB (compulsory: 419.6 / 553.9 MB)
-    (4096, "fused"): (530065964, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
-    (4096, "fused_resid"): (714790521, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
+    # the fused passes re-read halo lines / columns of neighbouring strips (28-line segments): 3 sweeps 2 x 202 257 KB +
+    # 133 028 KB, 3 sweeps + residual 2 x 206 821 KB + 266 428 KB, 3 sweeps with the correction folded in 2 x 246 947 KB
+    # + 133 111 KB (compulsory: 419.6 / 553.9 / 470.0 MB)
+    (4096, "fused"): (550442061, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
+    (4096, "fused_resid"): (696391880, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
+    (4096, "fused_prolong"): (642053580, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
 }
 
 
@@ -400,28 +402,35 @@ def main():
         with torch.cuda.stream(stream):
             ra = torch.empty_like(ya)
             fused = {}
-            for lab, k_, r_ in (("pre_smoothing_%d_sweeps_plus_residual" % min(nu, 3), min(nu, 3), ra),
-                                ("post_smoothing_%d_sweeps" % min(nu, 3), min(nu, 3), None)):
+            lev0 = H.levels[0]
+            with_corr = ops.stencil_smooth_prolong_available(fine_A, lev0.P)
+            ec = torch.zeros(lev0.P.shape[1], dtype=torch.float64, device=dev)
+            k3 = min(nu, 3)
+            for lab, k_, r_, corr in (("pre_smoothing_%d_sweeps_plus_residual" % k3, k3, ra, None),
+                                      ("post_smoothing_%d_sweeps%s" % (k3, "_with_correction" if with_corr else ""), k3, None,
+                                       (lev0.P, ec) if with_corr else None)):
                 for _ in range(2):
-                    ops.stencil_smooth(fine_A, xa, ba, args.omega, k_, ya, r_)
+                    ops.stencil_smooth(fine_A, xa, ba, args.omega, k_, ya, r_, prolong=corr)
                 ev0.record(stream)
                 for _ in range(20):
-                    ops.stencil_smooth(fine_A, xa, ba, args.omega, k_, ya, r_)
+                    ops.stencil_smooth(fine_A, xa, ba, args.omega, k_, ya, r_, prolong=corr)
                 ev1.record(stream)
                 torch.cuda.synchronize()
                 tf = ev0.elapsed_time(ev1) * 1e-3 / 20
-                moved = nrow * (1 + 24 + (8 if r_ is not None else 0))
-                napply = k_ + (1 if r_ is not None else 0)
-                pm = PMC_TRAFFIC.get((args.size, "fused_resid" if r_ is not None else "fused")) if (
+                # ids + x + b + out (+ r) (+ the ids of P and the coarse vector once)
+                moved = nrow * (1 + 24 + (8 if r_ is not None else 0)) + (nrow + 8 * ec.numel() if corr is not None else 0)
+                napply = k_ + (1 if r_ is not None else 0) + (1 if corr is not None else 0)
+                pm = PMC_TRAFFIC.get((args.size, "fused_resid" if r_ is not None else ("fused_prolong" if corr is not None else "fused"))) if (
                     args.problem == "poisson" and k_ == 3) else None
-                fused[lab] = {"kernel": "stencil_fused_kernel", "avg_launch_ms": tf * 1e3,
+                fused[lab] = {"kernel": "stencil_fused_kernel" + ("<PROL>: x + P e formed on the fly" if corr is not None else ""),
+                              "avg_launch_ms": tf * 1e3,
                               "traffic": None if pm is None else pm[0],
                               "traffic_source": None if pm is None else "%s (separate rocprofv3 --pmc passes, not this run)" % pm[1],
                               "operator_applications_per_launch": napply,
                               "compulsory_bytes_per_launch": moved, "GBps": moved / tf / 1e9,
                               "frac": moved / tf / 1e9 / HBM_PEAK_GBS,
                               "ms_per_operator_application": tf * 1e3 / napply,
-                              "separate_launches_would_take_ms": napply * t_jac * 1e3}
+                              "separate_launches_would_take_ms": (k_ + (1 if r_ is not None else 0)) * t_jac * 1e3}
             roofline["fused_passes_in_the_cycle"] = fused
     cyc_bytes, coarse_bytes = H.cycle_bytes(nu) if args.mode == "vcycle" and world == 1 else (None, None)
     if world > 1 or force_dist:

@@ -211,6 +211,24 @@ int lmg_stencil_smooth_prolong(int64_t n, int32_t line_stride, const uint8_t *d_
                                int32_t p_npat, const double *d_p_val, const int32_t *d_p_mask,
                                const int32_t *h_hot_pairs, const double *h_hot_pval, void *stream);
 
+/* The pre-smoothing pass with the restriction folded in (Multigrid.py:88 + :90 + :93 in one pass):
+ *     x_out = J^sweeps(x_in),   b_coarse = R (b - A x_out)
+ * for a restriction R whose row (Y, X) -- Y = row / coarse_stride, X = row % coarse_stride -- reads the fine
+ * residual only at  (2 Y * line_stride + 2 X) + c * line_stride + d,  c, d in {-1, 0, 1}  (slots 0..8,
+ * ascending columns): the transpose of the tensor-product interpolation, stored as row patterns (d_r_pid:
+ * one uint8 id per row of R; d_r_val [r_npat][9], d_r_mask [r_npat]).  The residual is never written: its last
+ * three lines stay in registers, and every coarse row is summed like lmg_rpat_sweep_grid(SPMV, alpha = 1,
+ * beta = 0) would, so b_coarse has the bits of residual + restriction launches.  Every fine node (even line,
+ * even column) must have its coarse row (LMG_ERR_ARG otherwise).  hot_r / h_hot_rval (HOST, 9 doubles): a
+ * pattern with all nine slots, or -1 / NULL.  d_x_in == NULL: zero initial iterate, as in lmg_stencil_smooth. */
+int lmg_stencil_smooth_restrict(int64_t n, int32_t line_stride, const uint8_t *d_pid, int32_t npat,
+                                const double *d_st_val, const int32_t *d_st_mask, uint32_t union_mask,
+                                int32_t hot_pattern, const double *h_hot_val, int sweeps, const double *d_x_in,
+                                const double *d_b, double omega, double *d_x_out, int64_t n_coarse,
+                                int32_t coarse_stride, double *d_b_coarse, const uint8_t *d_r_pid,
+                                int32_t r_npat, const double *d_r_val, const int32_t *d_r_mask, int32_t hot_r,
+                                const double *h_hot_rval, void *stream);
+
 /* ---- sliced-ELL ("SELL-64") sweeps: matrices with long rows ---------------------------
  * Third lossless twin.  Slice s = rows 64 s .. 64 s + 63, padded to its longest row
  * d_slice_len[s]; entry j of row r lives at d_slice_base[s] + 64 j + (r mod 64) of d_col

@@ -61,14 +61,26 @@ struct MArgs {
     int pp_npat;
     int hotp[2];              // even / odd lines: ids (A | B << 8) of the frequent pair of an (even, odd) column pair, or -1
     double hp[9];             // their values: even line A s0 | B s0 s1 || odd line A s0 s2 | B s0 s1 s2 s3
+    // REST: b_coarse = R r is formed on the fly instead of storing r (Multigrid.py:90 + :93 fused into the pre-smoothing
+    // pass): row (Y, X) of R reads r at lines 2Y - 1 .. 2Y + 1, columns 2X - 1 .. 2X + 1 (slots 0..8 like the operator)
+    double *bc;               // coarse right-hand side (output); nc, Wc as above
+    const unsigned char *rpid;    // pattern id of every row of R
+    const double *rp_val;     // [rp_npat][9]
+    const int *rp_mask;       // [rp_npat]
+    int rp_npat;
+    int hotr;                 // the frequent pattern with all nine slots, or -1
+    double hr[9];             // its values
 };
 
 // strip geometry: columns left of the stored part / stored columns of a 128-column window
-template <int H, bool PROL> struct StripGeom {
-    // PROL: the window starts on an even column (lane l then owns coarse column c0 / 2 + l) and its last pair is
-    // never exact (lane 63 has no right-hand coarse neighbour), so the right margin is H + 2 or more
-    static constexpr int ML = PROL ? ((H + 1) & ~1) : H;
-    static constexpr int U = PROL ? ((kStripCols - ML - (H + 2)) & ~1) : kStripCols - 2 * H;
+template <int H, bool PROL, bool REST> struct StripGeom {
+    // PROL and REST: the window starts on an even column (lane l then owns coarse column c0 / 2 + l).
+    // PROL: its last pair is never exact (lane 63 has no right-hand coarse neighbour): right margin H + 2 or more.
+    // REST: the residual must be exact one line / column beyond the stored part: margins H + 1 or more.
+    static constexpr bool EVEN = PROL || REST;
+    static constexpr int MLmin = REST ? H + 1 : H, MRmin = REST ? H + 1 : (PROL ? H + 2 : H);
+    static constexpr int ML = EVEN ? ((MLmin + 1) & ~1) : MLmin;
+    static constexpr int U = EVEN ? ((kStripCols - ML - MRmin) & ~1) : kStripCols - ML - MRmin;
 };
 
 __device__ __forceinline__ double dpp_lower(double src)      // lane i <- lane i-1, lane 0 <- 0
@@ -114,6 +126,7 @@ struct Line {
     d2 x, b;
     double e;       // PROL: coarse line (y + 1) >> 1 at the lane's coarse column
     int pp;         // PROL: the two pattern ids of P as loaded
+    int rp;         // REST: the pattern id of R's row (coarse line (y - S - 2) >> 1, the lane's coarse column)
     int praw;       // the two pattern ids as loaded (16 bits)
     int ok;         // bit 0 / 1: element 0 / 1 is a row of the matrix; bit 2 / 3: the pair was clamped
                     // up (i == -1) / down (i == n-1) and holds the wanted element in the other half
@@ -202,10 +215,11 @@ constexpr int kNBR = 6;         // depth of the b / id rings (>= S + 2)
 
 // UM: the union slot mask of the matrix, compile time (5-point, 9-point, 1-D chain: anything else runs
 // the separate sweeps) -- a run-time mask costs a scalar branch per slot, stage and line.
-template <int S, unsigned UM, bool RESID, bool ZERO, int PF, bool PROL = false>
+template <int S, unsigned UM, bool RESID, bool ZERO, int PF, bool PROL = false, bool REST = false>
 __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
 {
     static_assert(!PROL || (!RESID && !ZERO), "the correction is fused into post-smoothing passes only");
+    static_assert(!REST || (RESID && !PROL), "the restriction replaces the store of the residual");
     static_assert(kUF % 3 == 0 && kUF % kNBR == 0 && kUF % PF == 0 && S + 2 <= kNBR, "ring periods");
     constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);      // halo in lines and columns
     __shared__ double s_val[kMaxPat * 9];
@@ -213,6 +227,8 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
     __shared__ double s_rdiag[kMaxPat];
     __shared__ double s_pv[PROL ? kMaxPat * 4 : 1];
     __shared__ int s_pm[PROL ? kMaxPat : 1];
+    __shared__ double s_rv[REST ? kMaxPat * 9 : 1];
+    __shared__ int s_rm[REST ? kMaxPat : 1];
 #ifdef LMG_FUSED_TRACE
     __shared__ unsigned long long s_trace[64 * 8];
     for (int i = threadIdx.x; i < 64 * 8; i += kBlock) s_trace[i] = 0;
@@ -230,20 +246,25 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
         for (int i = t_; i < a.pp_npat * 4; i += kBlock) s_pv[i] = a.pp_val[i];
         for (int i = t_; i < a.pp_npat; i += kBlock) s_pm[i] = a.pp_mask[i];
     }
+    if (REST) {
+        for (int i = t_; i < a.rp_npat * 9; i += kBlock) s_rv[i] = a.rp_val[i];
+        for (int i = t_; i < a.rp_npat; i += kBlock) s_rm[i] = a.rp_mask[i];
+    }
     __syncthreads();
 
     const int lane = t_ & (LMG_WAVE - 1);
     const int item = (int)blockIdx.x * kWavesPerBlock + (t_ >> 6);
     if (item >= a.strips * a.segs) return;
     const int seg = item / a.strips, strip = item - seg * a.strips;
-    constexpr int U = StripGeom<H, PROL>::U, ML = StripGeom<H, PROL>::ML;   // columns a strip stores / its left margin
+    constexpr int U = StripGeom<H, PROL, REST>::U, ML = StripGeom<H, PROL, REST>::ML;   // columns a strip stores / its left margin
+    constexpr int HL = H + (REST ? 1 : 0);                       // halo in lines
     const int n = a.n;
     const int64_t W = a.W;
     const int c0 = strip * U - ML;                               // linear-index offset of lane 0's first element
     const int out_y0 = seg * a.seg_lines, out_y1 = min(a.lines, out_y0 + a.seg_lines);
-    // lines loaded: [y_begin, y_end); PROL starts on an even line, so that the parity of a step is a compile-time
-    // property of its place in the unrolled block
-    const int y_begin = out_y0 - H - (PROL ? ((out_y0 - H) & 1) : 0), y_end = out_y1 + H;
+    // lines loaded: [y_begin, y_end); PROL and REST start on an even line, so that the parity of a step is a
+    // compile-time property of its place in the unrolled block
+    const int y_begin = out_y0 - HL - ((PROL || REST) ? ((out_y0 - HL) & 1) : 0), y_end = out_y1 + HL;
     const int cidx = 2 * lane;                                   // window column of element 0
     // columns this lane may store (element 0 / 1): inside the strip's inner part and inside the line
     const bool colA = cidx >= ML && cidx < ML + U && c0 + cidx < W;
@@ -294,9 +315,24 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
             L.pp = 0;
             L.e = 0.0;
         }
+        if (REST) {
+            // the step that receives line y computes the residual of line y - S - 1 and, when that one is odd,
+            // the coarse line (y - S - 2) / 2 below it: its ids travel with line y
+            const int64_t jr = (int64_t)((y - S - 2) >> 1) * a.Wc + (c0 >> 1) + lane;
+            L.rp = (int)a.rpid[min(max(jr, (int64_t)0), (int64_t)a.nc - 1)];
+        } else {
+            L.rp = 0;
+        }
     };
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)n * 8u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(RESID ? a.r : a.out, 0, (int)((unsigned)n * 8u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((RESID && !REST) ? a.r : a.out, 0, (int)((unsigned)n * 8u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_bc = __builtin_amdgcn_make_buffer_rsrc(REST ? a.bc : a.out, 0, (int)((unsigned)(REST ? a.nc : n) * 8u), 0x00020000);
+    double hr[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) hr[s] = REST ? a.hr[s] : 0.0;
+    d2 RR[3];                                                     // REST: the last three residual lines
+    RR[0] = RR[1] = RR[2] = d2{0.0, 0.0};
+    int rp_now = 0;
     auto store2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, int p2, double va, double vb) {
         const bool yok = y >= out_y0 && y < out_y1;
         const int64_t i = (int64_t)y * W + c0 + cidx;
@@ -334,7 +370,7 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
 #pragma unroll
     for (int u = 0; u < PF; ++u) fetch(y_begin + u, pre[u]);
 
-    const int t_last = out_y1 - 1 + S + (RESID ? 1 : 0);         // last step that still produces output
+    const int t_last = out_y1 - 1 + S + (RESID ? 1 : 0) + (REST ? 1 : 0);   // last step that still produces output
 #ifdef LMG_FUSED_TRACE
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ck0 = __builtin_readcyclecounter();
 #endif
@@ -355,6 +391,7 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
                 xv.x = okA ? (down ? L.x.y : L.x.x) : 0.0;
                 xv.y = okB ? (up ? L.x.x : L.x.y) : 0.0;
                 const int pa = down ? (L.praw >> 8) & 0xff : L.praw & 0xff, pb = up ? L.praw & 0xff : (L.praw >> 8) & 0xff;
+                if (REST) rp_now = L.rp;
                 if (PROL) {
                     // x + P e_c for the two elements: row (y, x) of P reads e_c at ((y >> 1), (x >> 1)) + {0, 1} x {0, 1};
                     // both elements of a lane share x >> 1 = c0 / 2 + lane.  Same sums in the same order as
@@ -452,7 +489,43 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
                     const int pA = p2 & 0xff, pB = (p2 >> 8) & 0xff;
                     apply_rows<UM>(s_val, pA, pB, s_mask[pA], s_mask[pB], X[S][xm], X[S][xc], X[S][xp], accA, accB);
                 }
-                store2(rs_r, y, p2, Bq[q].x - accA, Bq[q].y - accB);
+                if (!REST) {
+                    store2(rs_r, y, p2, Bq[q].x - accA, Bq[q].y - accB);
+                } else {
+                    // b_c = R r without storing r: the residual lines stay in a ring of three; after an ODD line y the
+                    // coarse line (y - 1) / 2 has its three fine lines y - 2, y - 1, y.  Same sums in the same order as
+                    // lmg_rpat_sweep_grid(SPMV, alpha = 1, beta = 0): acc = 0; acc = acc + v * r per entry.
+                    d2 rr;
+                    rr.x = Bq[q].x - accA;
+                    rr.y = Bq[q].y - accB;
+                    RR[xc] = rr;
+                    const bool y_odd = ((u - S - 1) & 1) != 0;              // y_begin is even: compile time
+                    double bcv = 0.0;
+                    bool stc = false;
+                    if (y_odd) {
+                        const int xmm = ((u - S - 3) % 3 + 3) % 3;          // ring slot of line y - 2
+                        const d2 l0 = RR[xmm], l1 = RR[xm], l2 = RR[xc];
+                        const double w[9] = {dpp_lower(l0.y), l0.x, l0.y, dpp_lower(l1.y), l1.x, l1.y, dpp_lower(l2.y), l2.x, l2.y};
+                        const int yc2 = y - 1;                                // the fine line of the coarse row
+                        stc = yc2 >= out_y0 && yc2 < out_y1 && colA;          // this wave owns fine (yc2, c0 + cidx): an even, even node
+                        if (__all(!stc || rp_now == a.hotr)) {               // wave-uniform
+#pragma unroll
+                            for (int k = 0; k < 9; ++k) bcv = bcv + hr[k] * w[k];
+                        } else {
+                            const int mk = s_rm[rp_now];
+#pragma unroll
+                            for (int k = 0; k < 9; ++k) {
+                                const double tv = bcv + s_rv[rp_now * 9 + k] * w[k];
+                                bcv = ((mk >> k) & 1) ? tv : bcv;
+                            }
+                        }
+                    }
+                    const int jc = ((y - 1) >> 1) * a.Wc + (c0 >> 1) + lane;
+                    u2 v2;
+                    v2.x = (unsigned)__double2loint(bcv);
+                    v2.y = (unsigned)__double2hiint(bcv);
+                    __builtin_amdgcn_raw_buffer_store_b64(v2, rs_bc, (y_odd && stc) ? (unsigned)jc * 8u : kOOB, 0, 0);
+                }
             }
             LMG_TRACE(4);
         }
@@ -473,11 +546,11 @@ int g_fused_pf = 0;             // 0 = default
 int g_fused_want_waves = 5120;  // waves a launch aims at when it cuts the lines into segments ...
 int g_fused_floor_halos = 4;    // ... which are never shorter than this many halos (the redundant lines of a segment: 2 H)
 
-template <int S, unsigned UM, bool RESID, bool ZERO, bool PROL = false>
+template <int S, unsigned UM, bool RESID, bool ZERO, bool PROL = false, bool REST = false>
 int launch4(MArgs a, hipStream_t st)
 {
     constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);
-    constexpr int U = StripGeom<H, PROL>::U;
+    constexpr int U = StripGeom<H, PROL, REST>::U;
     a.strips = (a.W + U - 1) / U;
     // Segments: about 1.25 x the waves the chip holds at once (256 CUs x 16), never shorter than g_fused_floor_halos
     // halos.  Scanned in the cycle on one box (tools/ab_cycle.py, cfg#4): at 4097^2 the cycle takes 0.885 ms with
@@ -494,10 +567,10 @@ int launch4(MArgs a, hipStream_t st)
     a.segs = (a.lines + seg_lines - 1) / seg_lines;
     const int items = a.strips * a.segs;
     const int grid = (items + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (g_fused_pf == 3 && !PROL)
-        hipLaunchKernelGGL((stencil_fused_kernel<S, UM, RESID, ZERO, 3, false>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
+    if (g_fused_pf == 3 && !PROL && !REST)
+        hipLaunchKernelGGL((stencil_fused_kernel<S, UM, RESID, ZERO, 3, false, false>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
     else
-        hipLaunchKernelGGL((stencil_fused_kernel<S, UM, RESID, ZERO, 2, PROL>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
+        hipLaunchKernelGGL((stencil_fused_kernel<S, UM, RESID, ZERO, 2, PROL, REST>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }
@@ -516,6 +589,16 @@ int launch_prol(MArgs a, int sweeps, hipStream_t st)
     case 1: return launch4<1, UM, false, false, true>(a, st);
     case 2: return launch4<2, UM, false, false, true>(a, st);
     default: return launch4<3, UM, false, false, true>(a, st);
+    }
+}
+
+template <unsigned UM>
+int launch_rest(MArgs a, int sweeps, bool zero, hipStream_t st)
+{
+    switch (sweeps) {
+    case 1: return zero ? launch4<1, UM, true, true, false, true>(a, st) : launch4<1, UM, true, false, false, true>(a, st);
+    case 2: return zero ? launch4<2, UM, true, true, false, true>(a, st) : launch4<2, UM, true, false, false, true>(a, st);
+    default: return zero ? launch4<3, UM, true, true, false, true>(a, st) : launch4<3, UM, true, false, false, true>(a, st);
     }
 }
 
@@ -619,6 +702,13 @@ static int fill_args(MArgs &a, int64_t n, int32_t line_stride, const uint8_t *pi
     a.pp_npat = 0;
     a.hotp[0] = a.hotp[1] = -1;
     for (int k = 0; k < 9; ++k) a.hp[k] = 0.0;
+    a.bc = nullptr;
+    a.rpid = nullptr;
+    a.rp_val = nullptr;
+    a.rp_mask = nullptr;
+    a.rp_npat = 0;
+    a.hotr = -1;
+    for (int k = 0; k < 9; ++k) a.hr[k] = 0.0;
     return 1;                                  // filled: launch
 }
 
@@ -673,6 +763,44 @@ int lmg_stencil_smooth_prolong(int64_t n, int32_t line_stride, const uint8_t *pi
     switch (union_mask) {
     case kMask5: return launch_prol<kMask5>(a, sweeps, st);
     case kMask9: return launch_prol<kMask9>(a, sweeps, st);
+    default: return LMG_ERR_CAPACITY;
+    }
+}
+
+int lmg_stencil_smooth_restrict(int64_t n, int32_t line_stride, const uint8_t *pid, int32_t npat, const double *st_val,
+                                const int32_t *st_mask, uint32_t union_mask, int32_t hot_pattern, const double *h_hot_val,
+                                int sweeps, const double *x_in, const double *b, double omega, double *x_out,
+                                int64_t n_coarse, int32_t coarse_stride, double *b_coarse, const uint8_t *r_pid,
+                                int32_t r_npat, const double *r_val, const int32_t *r_mask, int32_t hot_r,
+                                const double *h_hot_rval, void *stream)
+{
+    if (!b_coarse || !r_pid || !r_val || !r_mask || r_npat < 1 || r_npat > kMaxPat) return LMG_ERR_ARG;
+    if (n_coarse < 1 || n_coarse >= (1ll << 28) || coarse_stride < 1 || coarse_stride > n_coarse) return LMG_ERR_ARG;
+    if ((const double *)b_coarse == x_in || b_coarse == x_out || (const double *)b_coarse == b) return LMG_ERR_ARG;
+    // row (Y, X) of R sits on the fine node (2 Y, 2 X): every such node of the fine grid must have its coarse row
+    const int64_t lines = n > 0 ? (n + line_stride - 1) / line_stride : 0;
+    if ((int64_t)coarse_stride < ((int64_t)line_stride + 1) / 2 || n_coarse < ((lines + 1) / 2 - 1) * coarse_stride + (line_stride + 1) / 2)
+        return LMG_ERR_ARG;
+    MArgs a;
+    const int rc = fill_args(a, n, line_stride, pid, npat, st_val, st_mask, union_mask, hot_pattern, h_hot_val, sweeps, x_in, b,
+                             omega, x_out, nullptr);
+    if (rc != 1) return rc;
+    a.bc = b_coarse;
+    a.nc = (int)n_coarse;
+    a.Wc = coarse_stride;
+    a.rpid = r_pid;
+    a.rp_val = r_val;
+    a.rp_mask = r_mask;
+    a.rp_npat = r_npat;
+    if (hot_r >= 0 && hot_r < r_npat && h_hot_rval) {
+        a.hotr = hot_r;
+        for (int k = 0; k < 9; ++k) a.hr[k] = h_hot_rval[k];
+    }
+    hipStream_t st = lmg_stream(stream);
+    const bool zero = x_in == nullptr;
+    switch (union_mask) {
+    case kMask5: return launch_rest<kMask5>(a, sweeps, zero, st);
+    case kMask9: return launch_rest<kMask9>(a, sweeps, zero, st);
     default: return LMG_ERR_CAPACITY;
     }
 }

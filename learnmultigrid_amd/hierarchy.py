@@ -237,7 +237,7 @@ class Hierarchy:
         avail = getattr(self.ops, "stencil_smooth_available", None)
         return (smoother == "Jacobi" and steps >= 1 and avail is not None and avail(self.levels[l].A))
 
-    def smooth_fused(self, l, steps, omega, x_is_zero=False, want_residual=False, correction=None):
+    def smooth_fused(self, l, steps, omega, x_is_zero=False, want_residual=False, correction=None, restrict_to=None):
         """`steps` Jacobi sweeps on level l (and r = b - A x afterwards) as fused passes of at most
         FUSED_MAX_SWEEPS sweeps each (lmg_stencil_smooth): same bits as smooth() + the residual launch,
         a third of the passes over the level's vectors.  correction = (P, e): the first pass starts from
@@ -251,6 +251,10 @@ class Hierarchy:
             if correction is not None:
                 self.ops.stencil_smooth(lev.A, lev.x, lev.b, omega, k, lev.tmp, None, prolong=correction)
                 correction = None
+            elif restrict_to is not None and left == 0:
+                # b_coarse = R (b - A x) formed in the pass, the residual itself is not written
+                self.ops.stencil_smooth(lev.A, None if x_is_zero else lev.x, lev.b, omega, k, lev.tmp, None,
+                                        restrict=restrict_to)
             else:
                 self.ops.stencil_smooth(lev.A, None if x_is_zero else lev.x, lev.b, omega, k, lev.tmp,
                                         lev.r if (want_residual and left == 0) else None)
@@ -272,7 +276,14 @@ class Hierarchy:
         last = (len(self.levels) if depth is None else depth) - 1
         lev, nxt = self.levels[l], self.levels[l + 1]
         fused = self._fusable(l, smoother, steps)
-        if fused:
+        ravail = getattr(self.ops, "stencil_smooth_restrict_available", None)
+        restricted = False
+        if fused and ravail is not None and ravail(lev.A, lev.R):
+            self.smooth_fused(l, steps, omega, x_is_zero, restrict_to=(lev.R, nxt.b))   # :88 + :90 + :93 in one pass
+            restricted = True
+            if after_presmooth is not None:
+                after_presmooth(lev.x)
+        elif fused:
             self.smooth_fused(l, steps, omega, x_is_zero, want_residual=True)  # :88 + :90 in one pass
             if after_presmooth is not None:
                 after_presmooth(lev.x)
@@ -281,7 +292,8 @@ class Hierarchy:
             if after_presmooth is not None:
                 after_presmooth(lev.x)
             self.ops.csr_residual_norm2(lev.A, lev.x, lev.b, lev.r, None, None)        # :90
-        self.ops.csr_spmv(lev.R, lev.r, nxt.b, 1.0, 0.0)                           # :93
+        if not restricted:
+            self.ops.csr_spmv(lev.R, lev.r, nxt.b, 1.0, 0.0)                       # :93
         if l + 1 == last:
             self.coarse_solve()                                               # :106
         else:

@@ -38,7 +38,7 @@ def _vec_ok(*ts):
 class DeviceCSR:
     """CSR matrix resident in HBM: int32 rowptr[n+1], int32 colidx[nnz], fp64 vals[nnz]."""
 
-    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz", "packed", "patterns", "sell", "stencil", "prolong")
+    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz", "packed", "patterns", "sell", "stencil", "prolong", "restrict")
 
     def __init__(self, rowptr, colidx, vals, shape):
         if rowptr.dtype != I32 or colidx.dtype != I32 or vals.dtype != F64:
@@ -53,6 +53,7 @@ class DeviceCSR:
         self.sell = None             # SellCSR twin (long rows with all-distinct values)
         self.stencil = None          # StencilTwin view of `patterns` (3x3 grid stencils), preferred
         self.prolong = None          # ProlongTwin view of `patterns` (2x2-window grid prolongations)
+        self.restrict = None         # RestrictTwin view of `patterns` (their transposes)
 
     def pack(self, patterns=None):
         """Build (once) the lossless twin the sweep kernels prefer; keeps the CSR arrays.
@@ -73,6 +74,7 @@ class DeviceCSR:
                         break
             self.stencil = StencilTwin.from_patterns(self.patterns, self.shape) if _STENCIL_ENABLED else None
             self.prolong = ProlongTwin.from_patterns(self.patterns, self.shape) if _STENCIL_ENABLED else None
+            self.restrict = RestrictTwin.from_patterns(self.patterns, self.shape) if _STENCIL_ENABLED else None
         if patterns and self.patterns is not None:
             return self.patterns
         if self.sell is not None:
@@ -97,6 +99,7 @@ class DeviceCSR:
         self.sell = None
         self.stencil = None
         self.prolong = None
+        self.restrict = None
 
     def repack_values(self):
         """After the values changed in place: refresh the twins (cheaply if possible)."""
@@ -104,6 +107,7 @@ class DeviceCSR:
             self.patterns = RowPatterns.from_csr(self, self.patterns.grid_map)
             self.stencil = StencilTwin.from_patterns(self.patterns, self.shape) if _STENCIL_ENABLED else None
             self.prolong = ProlongTwin.from_patterns(self.patterns, self.shape) if _STENCIL_ENABLED else None
+            self.restrict = RestrictTwin.from_patterns(self.patterns, self.shape) if _STENCIL_ENABLED else None
             if self.patterns is None:
                 self.pack()
         if self.sell is not None:
@@ -612,6 +616,58 @@ class ProlongTwin:
         return self
 
 
+class RestrictTwin:
+    """3x3-window view of the row-pattern twin of a RESTRICTION between nested grids for
+    lmg_stencil_smooth_restrict (see include/lmg.h): row (Y, X) of the coarse grid (line stride Wc) reads the
+    fine vector (line stride W) only at (2 Y * W + 2 X) + c * W + d, c, d in {-1, 0, 1} -- the transpose of the
+    tensor-product interpolation.  Derived on the host from the pattern table of a RowPatterns twin with the
+    column-base map (Wc, 2 W, 0, 0, 1); None for everything else (the restriction then is its own launch)."""
+
+    __slots__ = ("nc", "Wc", "n", "W", "npat", "pid", "r_val", "r_mask", "hot", "_hot_val", "patterns")
+
+    @classmethod
+    def from_patterns(cls, R, shape):
+        if R is None or R.grid_map is None or R.npat > 64:
+            return None
+        Wc, cs, ysh, xsh, xshl = R.grid_map
+        if (ysh, xsh, xshl) != (0, 0, 1) or cs % 2 or Wc < 2 or shape[0] >= 2 ** 28:
+            return None
+        W = cs // 2
+        if W < 3 or 2 * Wc < W + 1:
+            return None
+        ptr = R.pat_ptr.cpu().numpy()
+        off = R.pat_off.cpu().numpy().astype(np.int64)[: R.nent]
+        val = R.pat_val.cpu().numpy()[: R.nent]
+        r_val = np.zeros(R.npat * 9)
+        r_mask = np.zeros(R.npat, dtype=np.int32)
+        for p in range(R.npat):
+            o = off[ptr[p]:ptr[p + 1]]
+            if o.size > 9 or np.any(np.diff(o) <= 0):
+                return None
+            for j in range(ptr[p], ptr[p + 1]):
+                cd = StencilTwin._decompose(int(off[j]), W)
+                if cd is None:
+                    return None
+                k = (cd[0] + 1) * 3 + (cd[1] + 1)
+                if r_mask[p] & (1 << k):
+                    return None
+                r_mask[p] |= 1 << k
+                r_val[p * 9 + k] = val[j]
+        dev = R.pid.device
+        self = cls()
+        self.nc, self.Wc, self.n, self.W, self.npat = int(R.n), int(Wc), int(shape[1]), int(W), int(R.npat)
+        self.pid, self.patterns = R.pid, R
+        self.r_val = torch.from_numpy(r_val).to(dev)
+        self.r_mask = torch.from_numpy(r_mask).to(dev)
+        self.hot, self._hot_val = -1, None
+        cand = [p for p in range(R.npat) if r_mask[p] == 0x1FF]
+        if cand:
+            counts = torch.bincount(R.pid.long(), minlength=R.npat).cpu().numpy() if len(cand) > 1 else None
+            self.hot = int(cand[0] if counts is None else max(cand, key=lambda p: counts[p]))
+            self._hot_val = (ctypes.c_double * 9)(*[float(v) for v in r_val[self.hot * 9: self.hot * 9 + 9]])
+        return self
+
+
 _PACKED_ENABLED = True
 _PATTERNS_ENABLED = True
 _STENCIL_ENABLED = True
@@ -661,16 +717,30 @@ def set_fused_enabled(flag):
     _FUSED_ENABLED = bool(flag)
 
 
-def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None, prolong=None):
+def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None, prolong=None, restrict=None):
     """x_out = `sweeps` (1..3) weighted-Jacobi sweeps from x_in (None = zero iterate), r_out = b - A x_out
     (optional), in one pass (lmg_stencil_smooth); same bits as the separate csr_jacobi / vmul /
     csr_residual_norm2 launches.  prolong = (P, e): the sweeps start from x_in + P e (the correction of
-    Multigrid.py:115, never written: lmg_stencil_smooth_prolong; see stencil_smooth_prolong_available)."""
+    Multigrid.py:115, never written: lmg_stencil_smooth_prolong; see stencil_smooth_prolong_available).
+    restrict = (R, b_coarse): b_coarse = R (b - A x_out) instead of r_out (Multigrid.py:90 + :93, the residual is
+    never written: lmg_stencil_smooth_restrict; see stencil_smooth_restrict_available)."""
     _vec_ok(x_in, b, x_out, r_out)
     S = A.stencil
     if S is None:
         raise LmgError("stencil_smooth needs a grid-stencil matrix")
     hv = None if S._hot_val is None else ctypes.addressof(S._hot_val)
+    if restrict is not None:
+        R, bc = restrict
+        T = R.restrict
+        _vec_ok(bc)
+        if T is None or r_out is not None or prolong is not None or T.n != S.n or T.W != S.W or bc.numel() != T.nc:
+            raise LmgError("stencil_smooth: this restriction cannot be fused into the pass")
+        hr = None if T._hot_val is None else ctypes.addressof(T._hot_val)
+        check(_lib.lib().lmg_stencil_smooth_restrict(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask, S.hot,
+                                                     hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out), T.nc, T.Wc,
+                                                     _p(bc), _p(T.pid), T.npat, _p(T.r_val), _p(T.r_mask), T.hot, hr, _s()),
+              "lmg_stencil_smooth_restrict")
+        return
     if prolong is not None:
         P, e = prolong
         T = P.prolong
@@ -705,6 +775,28 @@ def stencil_smooth_prolong_available(A, P):
     S = getattr(A, "stencil", None)
     return bool(_FUSED_PROLONG_ENABLED and T is not None and stencil_smooth_available(A) and T.n == S.n and T.W == S.W
                 and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask))
+
+
+_FUSED_RESTRICT_ENABLED = True
+
+
+def set_fused_restrict_enabled(flag):
+    """Whether the restriction of the residual may be folded into the fused pre-smoothing pass (default) or the
+    residual is stored and restricted by its own launch (A/B runs and parity tests)."""
+    global _FUSED_RESTRICT_ENABLED
+    _FUSED_RESTRICT_ENABLED = bool(flag)
+
+
+def stencil_smooth_restrict_available(A, R):
+    """True when stencil_smooth can take `restrict=(R, b_coarse)`: A runs fused passes and R is the 3x3-window
+    restriction from A's grid with a coarse row under every (even line, even column) node."""
+    T = getattr(R, "restrict", None)
+    S = getattr(A, "stencil", None)
+    if not (_FUSED_RESTRICT_ENABLED and T is not None and stencil_smooth_available(A) and T.n == S.n and T.W == S.W
+            and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask)):
+        return False
+    lines = (S.n + S.W - 1) // S.W
+    return T.nc >= ((lines + 1) // 2 - 1) * T.Wc + (S.W + 1) // 2
 
 
 def _use_stencil(A, *vecs):

@@ -1128,6 +1128,54 @@ def test_fused_post_smoothing_with_the_correction_folded_in(m, kind, seg_lines):
         ops.tune_set("fused_seg_lines", 0)
 
 
+@pytest.mark.parametrize("m,kind", [(64, "5pt"), (150, "5pt"), (64, "9pt"), (129, "9pt")])
+@pytest.mark.parametrize("seg_lines", [0, 5, 6, 1000])
+def test_fused_pre_smoothing_with_the_restriction_folded_in(m, kind, seg_lines):
+    """lmg_stencil_smooth_restrict: x_out = J^S(x), b_c = R (b - A x_out) in one pass without storing the residual,
+    against the oracle's S Jacobi sweeps, residual and restriction (K.spmv with R = P^T), bitwise; zero and
+    non-zero initial iterates; segments that start on odd and even lines."""
+    side = 2 * m + 1
+    if kind == "5pt":
+        A = K.as_csr(P.poisson_2d_structured(side - 1)[0])
+    else:
+        Af = P.poisson_2d_structured(2 * (side - 1))[0]
+        Pf = P.tensor_interpolator_2d(2 * (side - 1) + 1)
+        A = K.as_csr(sp.csr_matrix(Pf.T @ Af @ Pf))
+    Rm = K.as_csr(sp.csr_matrix(sp.csr_matrix(P.tensor_interpolator_2d(side)).T))
+    n, nc = A.shape[0], Rm.shape[0]
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    dA.pack()
+    dR = ops.DeviceCSR.from_scipy(Rm, DEV)
+    dR.pack()
+    T = dR.restrict
+    assert dA.stencil is not None and T is not None and (T.W, T.Wc, T.nc, T.n) == (side, m + 1, nc, n) and T.hot >= 0
+    rng = np.random.default_rng(6)
+    x0, b = rng.standard_normal(n), rng.standard_normal(n)
+    try:
+        ops.tune_set("fused_seg_lines", seg_lines)
+        for zero in (False, True):
+            want = np.zeros(n) if zero else x0.copy()
+            for S in (1, 2, 3):
+                want = K.jacobi(A, want, b, 0.8)
+                wr, _ = K.residual(A, want, b)
+                wbc = K.spmv(Rm, wr)
+                out = torch.full((n,), np.nan, dtype=torch.float64, device=DEV)
+                bc = torch.full((nc,), np.nan, dtype=torch.float64, device=DEV)
+                ops.stencil_smooth(dA, None if zero else dev(x0), dev(b), 0.8, S, out, None, restrict=(dR, bc))
+                assert np.array_equal(out.cpu().numpy(), want), (m, kind, S, zero)
+                got = bc.cpu().numpy()
+                assert not np.isnan(got).any(), (m, kind, S, zero, np.flatnonzero(np.isnan(got))[:8])
+                assert np.array_equal(got, wbc), (m, kind, S, zero, np.flatnonzero(got != wbc)[:8])
+        # every coarse row through the pattern table instead of the frequent-pattern shortcut: same bits
+        hot, T.hot = T.hot, -1
+        bc = torch.full((nc,), np.nan, dtype=torch.float64, device=DEV)
+        ops.stencil_smooth(dA, None, dev(b), 0.8, 3, out, None, restrict=(dR, bc))
+        T.hot = hot
+        assert np.array_equal(bc.cpu().numpy(), wbc)
+    finally:
+        ops.tune_set("fused_seg_lines", 0)
+
+
 def test_prolong_twin_only_for_two_by_two_window_transfers():
     """ProlongTwin.from_patterns accepts the tensor-product interpolation and nothing wider: an L2-type
     transfer (3-point rows per axis) keeps its own launch."""
@@ -1139,6 +1187,12 @@ def test_prolong_twin_only_for_two_by_two_window_transfers():
     dQ = ops.DeviceCSR.from_scipy(sp.kron(l2, l2).tocsr(), DEV)
     dQ.pack()
     assert dQ.prolong is None
+    dR = dP.transpose()
+    dR.pack()
+    assert dR.restrict is not None and dP.restrict is None and dR.prolong is None
+    dQt = dQ.transpose()
+    dQt.pack()
+    assert dQt.restrict is None
     A = K.as_csr(P.poisson_2d_structured(32)[0])
     dA = ops.DeviceCSR.from_scipy(A, DEV)
     dA.pack()

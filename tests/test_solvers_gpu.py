@@ -402,6 +402,15 @@ def test_full_size_properties_4097():
         want = K.jacobi(Ac, want, b, 0.8)
     ops.stencil_smooth(dA, dx, db, 0.8, 3, out, None, prolong=(lev0.P, torch.from_numpy(e).to("cuda:0")))
     assert np.array_equal(out.cpu().numpy(), want)
+    # ... and the pre-smoothing pass with the restriction folded in (no residual vector is written)
+    assert ops.stencil_smooth_restrict_available(lev0.A, lev0.R) and ops.stencil_smooth_restrict_available(lev1.A, lev1.R)
+    want = x0
+    for _ in range(3):
+        want = K.jacobi(Ac, want, b, 0.8)
+    wbc = K.spmv(K.as_csr(sp.csr_matrix(hier[0]).T), K.residual(Ac, want, b)[0])
+    bc = torch.empty(Pm.shape[1], dtype=torch.float64, device="cuda:0")
+    ops.stencil_smooth(dA, dx, db, 0.8, 3, out, None, restrict=(lev0.R, bc))
+    assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(bc.cpu().numpy(), wbc)
 
 
 def test_g6_cg_matches_reference():

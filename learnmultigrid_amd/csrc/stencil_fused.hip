@@ -126,7 +126,7 @@ struct Line {
     d2 x, b;
     double e;       // PROL: coarse line (y + 1) >> 1 at the lane's coarse column
     int pp;         // PROL: the two pattern ids of P as loaded
-    int rp;         // REST: the pattern id of R's row (coarse line (y - S - 2) >> 1, the lane's coarse column)
+    int rp;         // REST: the pattern id of R's row (coarse line (y - S) >> 1, the lane's coarse column)
     int praw;       // the two pattern ids as loaded (16 bits)
     int ok;         // bit 0 / 1: element 0 / 1 is a row of the matrix; bit 2 / 3: the pair was clamped
                     // up (i == -1) / down (i == n-1) and holds the wanted element in the other half
@@ -216,7 +216,7 @@ constexpr int kNBR = 6;         // depth of the b / id rings (>= S + 2)
 // UM: the union slot mask of the matrix, compile time (5-point, 9-point, 1-D chain: anything else runs
 // the separate sweeps) -- a run-time mask costs a scalar branch per slot, stage and line.
 template <int S, unsigned UM, bool RESID, bool ZERO, int PF, bool PROL = false, bool REST = false>
-__global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
+__global__ void __launch_bounds__(kBlock, 3) stencil_fused_kernel(MArgs a)
 {
     static_assert(!PROL || (!RESID && !ZERO), "the correction is fused into post-smoothing passes only");
     static_assert(!REST || (RESID && !PROL), "the restriction replaces the store of the residual");
@@ -316,9 +316,9 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
             L.e = 0.0;
         }
         if (REST) {
-            // the step that receives line y computes the residual of line y - S - 1 and, when that one is odd,
-            // the coarse line (y - S - 2) / 2 below it: its ids travel with line y
-            const int64_t jr = (int64_t)((y - S - 2) >> 1) * a.Wc + (c0 >> 1) + lane;
+            // the step that receives line y computes the residual of line y - S - 1 and, when that one is odd, starts
+            // the coarse line (y - S) / 2 below it: its ids travel with line y
+            const int64_t jr = (int64_t)((y - S) >> 1) * a.Wc + (c0 >> 1) + lane;
             L.rp = (int)a.rpid[min(max(jr, (int64_t)0), (int64_t)a.nc - 1)];
         } else {
             L.rp = 0;
@@ -330,9 +330,9 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
     double hr[9];
 #pragma unroll
     for (int s = 0; s < 9; ++s) hr[s] = REST ? a.hr[s] : 0.0;
-    d2 RR[3];                                                     // REST: the last three residual lines
-    RR[0] = RR[1] = RR[2] = d2{0.0, 0.0};
-    int rp_now = 0;
+    double acc_cur = 0.0;                                         // REST: running sum of the coarse row in progress,
+    int rp_cur = 0, rp_now = 0;                                   //       its pattern id / the id that came with this line,
+    bool st_cur = false, hot_cur = false;                         //       whether this lane stores it / all storing lanes are hot
     auto store2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, int p2, double va, double vb) {
         const bool yok = y >= out_y0 && y < out_y1;
         const int64_t i = (int64_t)y * W + c0 + cidx;
@@ -492,39 +492,64 @@ __global__ void __launch_bounds__(kBlock) stencil_fused_kernel(MArgs a)
                 if (!REST) {
                     store2(rs_r, y, p2, Bq[q].x - accA, Bq[q].y - accB);
                 } else {
-                    // b_c = R r without storing r: the residual lines stay in a ring of three; after an ODD line y the
-                    // coarse line (y - 1) / 2 has its three fine lines y - 2, y - 1, y.  Same sums in the same order as
-                    // lmg_rpat_sweep_grid(SPMV, alpha = 1, beta = 0): acc = 0; acc = acc + v * r per entry.
-                    d2 rr;
-                    rr.x = Bq[q].x - accA;
-                    rr.y = Bq[q].y - accB;
-                    RR[xc] = rr;
-                    const bool y_odd = ((u - S - 1) & 1) != 0;              // y_begin is even: compile time
-                    double bcv = 0.0;
-                    bool stc = false;
-                    if (y_odd) {
-                        const int xmm = ((u - S - 3) % 3 + 3) % 3;          // ring slot of line y - 2
-                        const d2 l0 = RR[xmm], l1 = RR[xm], l2 = RR[xc];
-                        const double w[9] = {dpp_lower(l0.y), l0.x, l0.y, dpp_lower(l1.y), l1.x, l1.y, dpp_lower(l2.y), l2.x, l2.y};
-                        const int yc2 = y - 1;                                // the fine line of the coarse row
-                        stc = yc2 >= out_y0 && yc2 < out_y1 && colA;          // this wave owns fine (yc2, c0 + cidx): an even, even node
-                        if (__all(!stc || rp_now == a.hotr)) {               // wave-uniform
+                    // b_c = R r without storing r.  Row (Y, X) of R sums its entries in column order: slots 0..2 on line
+                    // 2Y - 1, 3..5 on line 2Y, 6..8 on line 2Y + 1 -- so the sum simply continues as the residual lines
+                    // go by: an ODD line finishes row (y - 1) / 2 (and stores it) and starts row (y + 1) / 2, an even
+                    // line adds the middle of its own row.  Two running sums per lane, no ring of residual lines; the
+                    // same products and sums in the same order as lmg_rpat_sweep_grid(SPMV, alpha = 1, beta = 0).
+                    const double rA = Bq[q].x - accA, rB = Bq[q].y - accB;
+                    const double wl[3] = {dpp_lower(rB), rA, rB};              // columns 2X - 1, 2X, 2X + 1
+                    const bool y_odd = ((u - S - 1) & 1) != 0;                 // y_begin is even: compile time
+                    unsigned off_bc = kOOB;
+                    double emit = 0.0;
+                    if (!y_odd) {
+                        if (hot_cur) {
 #pragma unroll
-                            for (int k = 0; k < 9; ++k) bcv = bcv + hr[k] * w[k];
+                            for (int k = 0; k < 3; ++k) acc_cur = acc_cur + hr[3 + k] * wl[k];
                         } else {
-                            const int mk = s_rm[rp_now];
+                            const int mk = s_rm[rp_cur];
 #pragma unroll
-                            for (int k = 0; k < 9; ++k) {
-                                const double tv = bcv + s_rv[rp_now * 9 + k] * w[k];
-                                bcv = ((mk >> k) & 1) ? tv : bcv;
+                            for (int k = 0; k < 3; ++k) {
+                                const double tv = acc_cur + s_rv[rp_cur * 9 + 3 + k] * wl[k];
+                                acc_cur = ((mk >> (3 + k)) & 1) ? tv : acc_cur;
+                            }
+                        }
+                    } else {
+                        // finish the row above ...
+                        if (hot_cur) {
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) acc_cur = acc_cur + hr[6 + k] * wl[k];
+                        } else {
+                            const int mk = s_rm[rp_cur];
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                const double tv = acc_cur + s_rv[rp_cur * 9 + 6 + k] * wl[k];
+                                acc_cur = ((mk >> (6 + k)) & 1) ? tv : acc_cur;
+                            }
+                        }
+                        emit = acc_cur;
+                        if (st_cur) off_bc = (unsigned)(((y - 1) >> 1) * a.Wc + (c0 >> 1) + lane) * 8u;
+                        // ... and start the row below: this wave owns it if it owns its fine node (y + 1, c0 + cidx)
+                        rp_cur = rp_now;
+                        st_cur = y + 1 >= out_y0 && y + 1 < out_y1 && colA;
+                        hot_cur = __all(!st_cur || rp_cur == a.hotr);
+                        acc_cur = 0.0;
+                        if (hot_cur) {
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) acc_cur = acc_cur + hr[k] * wl[k];
+                        } else {
+                            const int mk = s_rm[rp_cur];
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) {
+                                const double tv = acc_cur + s_rv[rp_cur * 9 + k] * wl[k];
+                                acc_cur = ((mk >> k) & 1) ? tv : acc_cur;
                             }
                         }
                     }
-                    const int jc = ((y - 1) >> 1) * a.Wc + (c0 >> 1) + lane;
                     u2 v2;
-                    v2.x = (unsigned)__double2loint(bcv);
-                    v2.y = (unsigned)__double2hiint(bcv);
-                    __builtin_amdgcn_raw_buffer_store_b64(v2, rs_bc, (y_odd && stc) ? (unsigned)jc * 8u : kOOB, 0, 0);
+                    v2.x = (unsigned)__double2loint(emit);
+                    v2.y = (unsigned)__double2hiint(emit);
+                    __builtin_amdgcn_raw_buffer_store_b64(v2, rs_bc, off_bc, 0, 0);
                 }
             }
             LMG_TRACE(4);

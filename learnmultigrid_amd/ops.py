@@ -758,6 +758,11 @@ def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None, prolong=None, r
           "lmg_stencil_smooth")
 
 
+# The transfers are folded into the fused passes only on levels that do not fit the Infinity Cache: what is saved is
+# HBM traffic (the residual / the corrected iterate are never written and re-read); on a cache-resident level the
+# passes are bound by their arithmetic and the extra work costs more than the two small launches it replaces
+# (measured in the cycle, cfg#4: 4097^2 5-point -52 us and -7 us, 2049^2 9-point +8 us and +4 us).
+FUSED_TRANSFER_MIN_ROWS = 8_000_000
 _FUSED_PROLONG_ENABLED = True
 
 
@@ -774,7 +779,7 @@ def stencil_smooth_prolong_available(A, P):
     T = getattr(P, "prolong", None)
     S = getattr(A, "stencil", None)
     return bool(_FUSED_PROLONG_ENABLED and T is not None and stencil_smooth_available(A) and T.n == S.n and T.W == S.W
-                and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask))
+                and S.n >= FUSED_TRANSFER_MIN_ROWS and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask))
 
 
 _FUSED_RESTRICT_ENABLED = True
@@ -793,7 +798,7 @@ def stencil_smooth_restrict_available(A, R):
     T = getattr(R, "restrict", None)
     S = getattr(A, "stencil", None)
     if not (_FUSED_RESTRICT_ENABLED and T is not None and stencil_smooth_available(A) and T.n == S.n and T.W == S.W
-            and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask)):
+            and S.n >= FUSED_TRANSFER_MIN_ROWS and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask)):
         return False
     lines = (S.n + S.W - 1) // S.W
     return T.nc >= ((lines + 1) // 2 - 1) * T.Wc + (S.W + 1) // 2

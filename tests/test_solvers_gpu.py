@@ -189,9 +189,10 @@ def test_fused_smoothing_passes_equal_separate_sweeps(m, levels, steps):
     kw = dict(levels=levels, smoother="Jacobi", smooth_steps=steps, max_iterations=6, error=1e-30,
               smoother_semantics="as_named", omega=0.8)
     runs = {}
-    min_rows = ops.FUSED_MIN_ROWS
+    min_rows, min_tr = ops.FUSED_MIN_ROWS, ops.FUSED_TRANSFER_MIN_ROWS
     try:
         ops.FUSED_MIN_ROWS = 0                       # (the product only fuses on multi-million-row levels)
+        ops.FUSED_TRANSFER_MIN_ROWS = 0
         for fused in (False, True):
             ops.set_fused_enabled(fused)
             for graph in (False, True):
@@ -202,6 +203,7 @@ def test_fused_smoothing_passes_equal_separate_sweeps(m, levels, steps):
     finally:
         ops.set_fused_enabled(True)
         ops.FUSED_MIN_ROWS = min_rows
+        ops.FUSED_TRANSFER_MIN_ROWS = min_tr
     t0, x0 = runs[False, False]
     for key, (t, x) in runs.items():
         assert np.array_equal(t, t0) and np.array_equal(x, x0), key
@@ -394,7 +396,7 @@ def test_full_size_properties_4097():
     # ... and the post-smoothing pass with the coarse-grid correction folded in (what the cycle above ran on the
     # two finest levels): prolongation + 3 sweeps of the oracle, bitwise
     lev0, lev1 = mg._hier.levels[0], mg._hier.levels[1]
-    assert ops.stencil_smooth_prolong_available(lev0.A, lev0.P) and ops.stencil_smooth_prolong_available(lev1.A, lev1.P)
+    assert ops.stencil_smooth_prolong_available(lev0.A, lev0.P) and not ops.stencil_smooth_prolong_available(lev1.A, lev1.P)
     Pm = K.as_csr(hier[0])
     e = rng.standard_normal(Pm.shape[1])
     want = K.spmv(Pm, e, x0.copy(), 1.0, 1.0)
@@ -403,7 +405,7 @@ def test_full_size_properties_4097():
     ops.stencil_smooth(dA, dx, db, 0.8, 3, out, None, prolong=(lev0.P, torch.from_numpy(e).to("cuda:0")))
     assert np.array_equal(out.cpu().numpy(), want)
     # ... and the pre-smoothing pass with the restriction folded in (no residual vector is written)
-    assert ops.stencil_smooth_restrict_available(lev0.A, lev0.R) and ops.stencil_smooth_restrict_available(lev1.A, lev1.R)
+    assert ops.stencil_smooth_restrict_available(lev0.A, lev0.R) and not ops.stencil_smooth_restrict_available(lev1.A, lev1.R)
     want = x0
     for _ in range(3):
         want = K.jacobi(Ac, want, b, 0.8)

@@ -42,12 +42,14 @@ PMC_TRAFFIC = {
     (4096, "pcsr"): (672639665, "profiles/r01_packed_sweep_pmc_fetch_write.txt"),
     (4096, "rpat"): (451701453, "profiles/r01_rpat_sweep_pmc_fetch_write.txt"),
     (4096, "stencil"): (420151166, "profiles/r02_stencil_sweep_pmc_fetch_write.txt"),
-    # the fused passes re-read halo lines / columns of neighbouring strips (28-line segments): 3 sweeps 2 x 202 257 KB +
-    # 133 028 KB, 3 sweeps + residual 2 x 206 821 KB + 266 428 KB, 3 sweeps with the correction folded in 2 x 246 947 KB
-    # + 133 111 KB (compulsory: 419.6 / 553.9 / 470.0 MB)
-    (4096, "fused"): (550442061, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
-    (4096, "fused_resid"): (696391880, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
-    (4096, "fused_prolong"): (642053580, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
+    # the fused passes re-read halo lines / columns of neighbouring strips (28-line segments): 3 sweeps 2 x 202 071 KB +
+    # 133 019 KB; + residual 2 x 206 830 KB + 266 434 KB; + restricted residual (r not written) 2 x 235 383 KB +
+    # 167 046 KB; 3 sweeps with the correction folded in 2 x 247 234 KB + 132 993 KB
+    # (compulsory: 419.6 / 553.9 / 457.4 / 470.0 MB)
+    (4096, "fused"): (550052414, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
+    (4096, "fused_resid"): (696414816, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
+    (4096, "fused_restrict"): (653118214, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
+    (4096, "fused_prolong"): (642520154, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
 }
 
 
@@ -404,25 +406,33 @@ def main():
             fused = {}
             lev0 = H.levels[0]
             with_corr = ops.stencil_smooth_prolong_available(fine_A, lev0.P)
+            with_rest = ops.stencil_smooth_restrict_available(fine_A, lev0.R)
             ec = torch.zeros(lev0.P.shape[1], dtype=torch.float64, device=dev)
+            bcv = torch.zeros_like(ec)
             k3 = min(nu, 3)
-            for lab, k_, r_, corr in (("pre_smoothing_%d_sweeps_plus_residual" % k3, k3, ra, None),
-                                      ("post_smoothing_%d_sweeps%s" % (k3, "_with_correction" if with_corr else ""), k3, None,
-                                       (lev0.P, ec) if with_corr else None)):
+            for lab, k_, r_, corr, rest in (
+                    ("pre_smoothing_%d_sweeps_plus_%s" % (k3, "restricted_residual" if with_rest else "residual"), k3,
+                     None if with_rest else ra, None, (lev0.R, bcv) if with_rest else None),
+                    ("post_smoothing_%d_sweeps%s" % (k3, "_with_correction" if with_corr else ""), k3, None,
+                     (lev0.P, ec) if with_corr else None, None)):
                 for _ in range(2):
-                    ops.stencil_smooth(fine_A, xa, ba, args.omega, k_, ya, r_, prolong=corr)
+                    ops.stencil_smooth(fine_A, xa, ba, args.omega, k_, ya, r_, prolong=corr, restrict=rest)
                 ev0.record(stream)
                 for _ in range(20):
-                    ops.stencil_smooth(fine_A, xa, ba, args.omega, k_, ya, r_, prolong=corr)
+                    ops.stencil_smooth(fine_A, xa, ba, args.omega, k_, ya, r_, prolong=corr, restrict=rest)
                 ev1.record(stream)
                 torch.cuda.synchronize()
                 tf = ev0.elapsed_time(ev1) * 1e-3 / 20
-                # ids + x + b + out (+ r) (+ the ids of P and the coarse vector once)
-                moved = nrow * (1 + 24 + (8 if r_ is not None else 0)) + (nrow + 8 * ec.numel() if corr is not None else 0)
-                napply = k_ + (1 if r_ is not None else 0) + (1 if corr is not None else 0)
-                pm = PMC_TRAFFIC.get((args.size, "fused_resid" if r_ is not None else ("fused_prolong" if corr is not None else "fused"))) if (
-                    args.problem == "poisson" and k_ == 3) else None
-                fused[lab] = {"kernel": "stencil_fused_kernel" + ("<PROL>: x + P e formed on the fly" if corr is not None else ""),
+                # ids + x + b + out (+ r) (+ the ids of P and the coarse vector once) (+ the ids of R and the coarse rhs)
+                moved = (nrow * (1 + 24 + (8 if r_ is not None else 0)) + (nrow + 8 * ec.numel() if corr is not None else 0)
+                         + (9 * ec.numel() if rest is not None else 0))
+                has_resid = r_ is not None or rest is not None
+                napply = k_ + (1 if has_resid else 0) + (1 if (corr is not None or rest is not None) else 0)
+                key = "fused_restrict" if rest is not None else ("fused_resid" if r_ is not None else
+                                                                 ("fused_prolong" if corr is not None else "fused"))
+                pm = PMC_TRAFFIC.get((args.size, key)) if (args.problem == "poisson" and k_ == 3) else None
+                fused[lab] = {"kernel": "stencil_fused_kernel" + ("<PROL>: x + P e formed on the fly" if corr is not None else
+                                                                  ("<REST>: R r formed on the fly, r not written" if rest is not None else "")),
                               "avg_launch_ms": tf * 1e3,
                               "traffic": None if pm is None else pm[0],
                               "traffic_source": None if pm is None else "%s (separate rocprofv3 --pmc passes, not this run)" % pm[1],
@@ -430,7 +440,7 @@ def main():
                               "compulsory_bytes_per_launch": moved, "GBps": moved / tf / 1e9,
                               "frac": moved / tf / 1e9 / HBM_PEAK_GBS,
                               "ms_per_operator_application": tf * 1e3 / napply,
-                              "separate_launches_would_take_ms": (k_ + (1 if r_ is not None else 0)) * t_jac * 1e3}
+                              "separate_launches_would_take_ms": (k_ + (1 if has_resid else 0)) * t_jac * 1e3}
             roofline["fused_passes_in_the_cycle"] = fused
     cyc_bytes, coarse_bytes = H.cycle_bytes(nu) if args.mode == "vcycle" and world == 1 else (None, None)
     if world > 1 or force_dist:

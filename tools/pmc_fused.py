@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The fine-level kernels of the cfg#4 cycle, five launches each, for counter passes:
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out -- python3 tools/pmc_fused.py      (and WRITE_SIZE, SQ counters)
-Launches: fused 3 sweeps + residual, fused 3 sweeps with the correction folded in, fused 3 sweeps, one stencil
+Launches: fused 3 sweeps + residual, the same with the restriction folded in, fused 3 sweeps with the correction folded in, fused 3 sweeps, one stencil
 sweep, restriction, prolongation -- on 4097^2 / 2049^2 (tensor-product transfer)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,6 +21,7 @@ y = torch.empty_like(x); r = torch.empty_like(x)
 e = torch.rand(nc, dtype=torch.float64, device=dev); bc = torch.empty_like(e)
 for _ in range(5):
     ops.stencil_smooth(dA, x, b, 0.8, 3, y, r)
+    ops.stencil_smooth(dA, x, b, 0.8, 3, y, None, restrict=(dR, bc))
     ops.stencil_smooth(dA, x, b, 0.8, 3, y, None, prolong=(dP, e))
     ops.stencil_smooth(dA, x, b, 0.8, 3, y, None)
     ops.csr_jacobi(dA, x, b, 0.8, y)

@@ -190,6 +190,16 @@ int lmg_stencil_smooth(int64_t n, int32_t line_stride, const uint8_t *d_pid, int
                        int32_t hot_pattern, const double *h_hot_val, int sweeps, const double *d_x_in,
                        const double *d_b, double omega, double *d_x_out, double *d_r_out, void *stream);
 
+/* The same pass for SMALL levels (10^4 .. 10^6 rows), iterates in LDS instead of registers: a workgroup owns a tile
+ * of 64 columns x 16 / 32 lines, loads it once, runs the sweeps between two LDS buffers and stores its inner part
+ * (csrc/stencil_tile.hip): one launch instead of sweeps + 1, same bits.  Same arguments as lmg_stencil_smooth;
+ * 5- and 9-point union masks (lmg_stencil_smooth_tiled_supported). */
+int lmg_stencil_smooth_tiled_supported(uint32_t union_mask);
+int lmg_stencil_smooth_tiled(int64_t n, int32_t line_stride, const uint8_t *d_pid, int32_t npat,
+                             const double *d_st_val, const int32_t *d_st_mask, uint32_t union_mask,
+                             int32_t hot_pattern, const double *h_hot_val, int sweeps, const double *d_x_in,
+                             const double *d_b, double omega, double *d_x_out, double *d_r_out, void *stream);
+
 /* The same pass with the coarse-grid correction folded in (Multigrid.py:115 + :121 in one pass):
  *     x_out = J^sweeps(x_in + P e_coarse)
  * for a prolongation P whose row (y, x) -- y = row / line_stride, x = row % line_stride -- reads

@@ -1,0 +1,356 @@
+// Fused smoothing passes for SMALL grid-stencil levels (format of stencil.hip) for gfx950:
+//     x_out = J^S(x_in)   [r = b - A x_out]          S = 1..3 weighted-Jacobi sweeps, x_in == NULL: zero iterate
+// -- what stencil_fused.hip does for the multi-million-row levels, with the iterates in LDS instead of registers.
+// On a level of 10^4 .. 10^6 rows a sweep is a 2 - 7 us launch (tools/time_small.py) and the register kernel is no
+// help: a wave there walks 12 - 40 lines one after the other, 2 100 cycles each.  Here a WORKGROUP owns a tile of
+// 64 columns x RR lines (its inner 64 - 2H x RR - 2H part is what it stores; H = S, +1 with the residual, -1 from a
+// zero iterate), loads it once -- x, b, pattern ids --, runs the S sweeps between two LDS buffers with all four
+// waves working on different lines of the same sweep, and stores the inner part: S (+1) launches become one, the
+// dependent chain is S + 2 barriers long instead of S (+1) kernel boundaries.
+// The arithmetic per row and sweep is the instruction sequence of stencil_sweep_kernel (slot order, separate
+// multiply and add, omega * (rdiag * r)), so every value is bit-identical to the separate launches; as in
+// stencil_fused.hip everything is a LINEAR index i = line * W + column, a column outside [0, W) being the linear
+// neighbour in the adjacent line.
+#include <string.h>
+#include "lmg_common.hpp"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / LMG_WAVE;
+constexpr int kMaxPat = 64;
+constexpr int kCols = 64;                     // columns of a tile = lanes of a wave
+constexpr int kLS = kCols + 2;                // LDS line stride: one guard column on either side
+constexpr unsigned kMask5 = 0x0BAu;
+constexpr unsigned kMask9 = 0x1FFu;
+
+__device__ __forceinline__ double dpp_lower(double src)      // lane i <- lane i-1, lane 0 <- 0
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double dpp_upper(double src)      // lane i <- lane i+1, lane 63 <- 0
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+struct TArgs {
+    int n, W, lines, npat;
+    int tiles_x, tiles_y;
+    const unsigned char *pid;
+    const double *st_val;
+    const int *st_mask;
+    const double *x;          // may be NULL with ZERO
+    const double *b;
+    double *out;
+    double *r;                // may be NULL without RESID
+    double omega;
+    int hot;
+    double hot_val[9];
+    double hot_rdiag;
+};
+
+template <int S, unsigned UM, bool RESID, bool ZERO, int RR>
+__global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
+{
+    constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);
+    static_assert(RR > 2 * H + 1 && kCols > 2 * H, "tile smaller than its halo");
+    __shared__ double s_x[2][RR * kLS];
+    __shared__ double s_b[RR * kLS];
+    __shared__ unsigned short s_p[RR * kCols];             // pattern id | 0x100 where the element is a row of the matrix
+    __shared__ double s_val[kMaxPat * 9];
+    __shared__ int s_mask[kMaxPat];
+    __shared__ double s_rdiag[kMaxPat];
+
+    const int t = threadIdx.x, lane = t & (LMG_WAVE - 1), wave = t >> 6;
+    const int tx = (int)blockIdx.x % a.tiles_x, ty = (int)blockIdx.x / a.tiles_x;
+    const int c0 = tx * (kCols - 2 * H) - H, y0 = ty * (RR - 2 * H) - H;
+    const int n = a.n;
+    const int64_t W = a.W;
+
+    // ---- the tile's lines are requested first, the pattern table is staged while they are in flight ----------
+    constexpr int kPer = (RR + kWaves - 1) / kWaves;
+    double lx[kPer], lb[kPer];
+    int lp[kPer];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int r = wave + k * kWaves;
+        const int y = y0 + r;
+        const int64_t i = (int64_t)y * W + c0 + lane;
+        const bool ok = r < RR && y >= 0 && y < a.lines && i >= 0 && i < n;
+        const int64_t j = ok ? i : 0;
+        lx[k] = (!ZERO && ok) ? a.x[j] : 0.0;
+        lb[k] = ok ? a.b[j] : 0.0;
+        lp[k] = ok ? ((int)a.pid[j] | 0x100) : 0;
+    }
+    for (int i = t; i < a.npat * 9; i += kBlock) s_val[i] = a.st_val[i];
+    for (int i = t; i < a.npat; i += kBlock) {
+        const int m = a.st_mask[i];
+        const double dg = (m & 16) ? a.st_val[i * 9 + 4] : 0.0;
+        s_rdiag[i] = dg != 0.0 ? 1.0 / dg : 0.0;
+        s_mask[i] = dg == 0.0 ? (m | (1 << 16)) : m;             // bit 16: no usable diagonal -> copy x
+    }
+    for (int i = t; i < 2 * RR; i += kBlock) {                    // guard columns of both iterate buffers
+        const int r = i >> 1, g = (i & 1) ? kLS - 1 : 0;
+        s_x[0][r * kLS + g] = 0.0;
+        s_x[1][r * kLS + g] = 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+        const int r = wave + k * kWaves;
+        if (r < RR) {
+            s_x[0][r * kLS + 1 + lane] = lx[k];
+            s_x[1][r * kLS + 1 + lane] = 0.0;
+            s_b[r * kLS + 1 + lane] = lb[k];
+            s_p[r * kCols + lane] = (unsigned short)lp[k];
+        }
+    }
+    __syncthreads();
+
+    const double omega = a.omega;
+    const int hot = a.hot >= 0 ? (a.hot | 0x100) : -1;
+    double hv[9];
+#pragma unroll
+    for (int s = 0; s < 9; ++s) hv[s] = a.hot_val[s];
+    const double hrd = a.hot_rdiag;
+
+    // Each wave owns RB consecutive lines of the tile and slides a three-line window down them: the centre values
+    // of a new line come from LDS (one 8-byte read per lane), its left / right neighbours from the neighbouring
+    // lanes (DPP; lanes 0 / 63 get the zero of the guard columns -- they are halo), so a line costs one LDS read of
+    // x instead of nine.
+    constexpr int RB = RR / kWaves;
+    static_assert(RR % kWaves == 0, "lines per wave");
+    constexpr bool DIAG = (UM & 0x145u) != 0;
+    const int rb0 = wave * RB;
+    struct Win { double m, c, p; };
+    auto line = [&](const double *src, int r, bool sides) -> Win {
+        Win w;
+        w.c = src[r * kLS + 1 + lane];
+        w.m = sides ? dpp_lower(w.c) : 0.0;
+        w.p = sides ? dpp_upper(w.c) : 0.0;
+        return w;
+    };
+    // A x of the centre line of (u, c, d) for this lane, slot order = column order
+    auto apply = [&](const Win &u, const Win &c, const Win &d, int p, bool all_hot) -> double {
+        const double w[9] = {u.m, u.c, u.p, c.m, c.c, c.p, d.m, d.c, d.p};
+        double acc = 0.0;
+        if (all_hot) {
+#pragma unroll
+            for (int s = 0; s < 9; ++s)
+                if ((UM >> s) & 1u) acc = acc + hv[s] * w[s];
+        } else {
+            const int q = p & 0xff, m = s_mask[q];
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                if (!((UM >> s) & 1u)) continue;
+                const double tv = acc + s_val[q * 9 + s] * w[s];
+                acc = ((m >> s) & 1) ? tv : acc;
+            }
+        }
+        return acc;
+    };
+
+    // One block of RB lines, straight-line: all its lines are read first, then either every lane of every line holds
+    // the frequent pattern (values in scalar registers) or every line goes through the pattern table -- no branch
+    // inside either path, so the LDS latencies and the dependent sums of the RB lines overlap.  Lines outside
+    // [lo, hi) are computed from clamped (meaningless) neighbours and not stored.
+    auto block = [&](const double *src, int lo, int hi, auto &&emit) {
+        Win ln[RB + 2];
+#pragma unroll
+        for (int j = 0; j < RB + 2; ++j) {
+            const int rr = min(max(rb0 - 1 + j, 0), RR - 1);
+            ln[j] = line(src, rr, DIAG || (j >= 1 && j <= RB));
+        }
+        int pk[RB];
+        double bk[RB];
+        bool mine = true;
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            pk[k] = s_p[(rb0 + k) * kCols + lane];
+            bk[k] = s_b[(rb0 + k) * kLS + 1 + lane];
+            mine = mine && (pk[k] == hot || !(pk[k] >> 8));      // (elements outside the matrix are not stored)
+        }
+        if (__all(mine)) {                                         // wave-uniform
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const double acc = apply(ln[k], ln[k + 1], ln[k + 2], pk[k], true);
+                emit(rb0 + k, rb0 + k >= lo && rb0 + k < hi, pk[k], true, ln[k + 1].c, bk[k], acc);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const double acc = apply(ln[k], ln[k + 1], ln[k + 2], pk[k], false);
+                emit(rb0 + k, rb0 + k >= lo && rb0 + k < hi, pk[k], false, ln[k + 1].c, bk[k], acc);
+            }
+        }
+    };
+
+    // ---- the sweeps: iterate s goes from buffer (s - 1) & 1 to buffer s & 1 -------------------------------------
+#pragma unroll
+    for (int s = 1; s <= S; ++s) {
+        const double *src = s_x[(s - 1) & 1];
+        double *dst = s_x[s & 1];
+        if (ZERO && s == 1) {
+            // first sweep from a zero iterate: x = omega * (D^-1 b) on every line (lmg_vmul's bits)
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const int r = rb0 + k;
+                const int p = s_p[r * kCols + lane];
+                const double bv = s_b[r * kLS + 1 + lane];
+                dst[r * kLS + 1 + lane] = (p >> 8) ? omega * (s_rdiag[p & 0xff] * bv) : 0.0;
+            }
+        } else {
+            // (lines 0 and RR - 1 have no line above / below)
+            block(src, 1, RR - 1, [&](int r, bool keep, int p, bool all_hot, double xc, double bv, double acc) {
+                const double res = bv - acc;
+                double nx;
+                if (all_hot) {
+                    nx = xc + omega * (hrd * res);
+                } else {
+                    const int q = p & 0xff;
+                    nx = (s_mask[q] >> 16) ? xc : xc + omega * (s_rdiag[q] * res);
+                }
+                if (keep) dst[r * kLS + 1 + lane] = (p >> 8) ? nx : 0.0;
+            });
+        }
+        __syncthreads();
+    }
+
+    // ---- outputs: the inner part of the tile, inside the line, rows of the matrix --------------------------------
+    const double *fin = s_x[S & 1];
+    const bool col_ok = lane >= H && lane < kCols - H && c0 + lane >= 0 && c0 + lane < W;
+    if (RESID) {
+        block(fin, H, RR - H, [&](int r, bool keep, int p, bool, double xc, double bv, double acc) {
+            const int64_t i = (int64_t)(y0 + r) * W + c0 + lane;
+            if (keep && col_ok && (p >> 8)) {
+                a.out[i] = xc;
+                a.r[i] = bv - acc;
+            }
+        });
+    } else {
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            const int r = rb0 + k;
+            if (r >= H && r < RR - H) {
+                const int p = s_p[r * kCols + lane];
+                const int64_t i = (int64_t)(y0 + r) * W + c0 + lane;
+                if (col_ok && (p >> 8)) a.out[i] = fin[r * kLS + 1 + lane];
+            }
+        }
+    }
+}
+
+int g_tile_rows = 0;        // 0 = chosen per launch (tuning: 16, 24, 32)
+
+template <int S, unsigned UM, bool RESID, bool ZERO, int RR>
+int launch5(TArgs a, hipStream_t st)
+{
+    constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);
+    a.tiles_x = (a.W + (kCols - 2 * H) - 1) / (kCols - 2 * H);
+    a.tiles_y = (a.lines + (RR - 2 * H) - 1) / (RR - 2 * H);
+    const int64_t grid = (int64_t)a.tiles_x * a.tiles_y;
+    if (grid > 0x7fffffff) return LMG_ERR_CAPACITY;
+    hipLaunchKernelGGL((stencil_tile_kernel<S, UM, RESID, ZERO, RR>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+template <int S, unsigned UM, bool RESID, bool ZERO>
+int launch4(TArgs a, hipStream_t st)
+{
+    int rr = g_tile_rows;
+    if (rr == 0) rr = 16;         // measured in the cycle (cfg#4): 0.780 ms with 16-line tiles, 0.795 with 24, 0.814 with 32
+    switch (rr) {
+    case 16: return launch5<S, UM, RESID, ZERO, 16>(a, st);
+    case 24: return launch5<S, UM, RESID, ZERO, 24>(a, st);
+    default: return launch5<S, UM, RESID, ZERO, 32>(a, st);
+    }
+}
+
+template <int S, unsigned UM>
+int launch2(TArgs a, bool resid, bool zero, hipStream_t st)
+{
+    if (resid) return zero ? launch4<S, UM, true, true>(a, st) : launch4<S, UM, true, false>(a, st);
+    return zero ? launch4<S, UM, false, true>(a, st) : launch4<S, UM, false, false>(a, st);
+}
+
+template <unsigned UM>
+int launch1(TArgs a, int sweeps, bool resid, bool zero, hipStream_t st)
+{
+    switch (sweeps) {
+    case 1: return launch2<1, UM>(a, resid, zero, st);
+    case 2: return launch2<2, UM>(a, resid, zero, st);
+    default: return launch2<3, UM>(a, resid, zero, st);
+    }
+}
+
+}  // namespace
+
+int lmg_tile_tune_set(const char *key, int v)
+{
+    if (strcmp(key, "tile_rows") == 0) {
+        if (v != 0 && v != 16 && v != 24 && v != 32) return LMG_ERR_ARG;
+        g_tile_rows = v;
+        return LMG_OK;
+    }
+    return LMG_ERR_ARG;
+}
+int lmg_tile_tune_get(const char *key)
+{
+    if (strcmp(key, "tile_rows") == 0) return g_tile_rows;
+    return LMG_ERR_ARG;
+}
+
+extern "C" {
+
+int lmg_stencil_smooth_tiled(int64_t n, int32_t line_stride, const uint8_t *pid, int32_t npat, const double *st_val,
+                             const int32_t *st_mask, uint32_t union_mask, int32_t hot_pattern, const double *h_hot_val,
+                             int sweeps, const double *x_in, const double *b, double omega, double *x_out, double *r_out,
+                             void *stream)
+{
+    if (n < 0 || n >= (1ll << 31) - 4096 || npat < 1 || npat > kMaxPat || (union_mask & ~0x1FFu)) return LMG_ERR_ARG;
+    if (sweeps < 1 || sweeps > 3) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    if (!pid || !st_val || !st_mask || !b || !x_out || x_in == x_out || r_out == x_out || (r_out && r_out == x_in))
+        return LMG_ERR_ARG;
+    if (line_stride < 3 || line_stride > n) return LMG_ERR_ARG;
+    TArgs a;
+    a.n = (int)n;
+    a.W = line_stride;
+    a.lines = (int)((n + line_stride - 1) / line_stride);
+    a.npat = npat;
+    a.tiles_x = a.tiles_y = 0;
+    a.pid = pid;
+    a.st_val = st_val;
+    a.st_mask = st_mask;
+    a.x = x_in;
+    a.b = b;
+    a.out = x_out;
+    a.r = r_out;
+    a.omega = omega;
+    a.hot = -1;
+    for (int k = 0; k < 9; ++k) a.hot_val[k] = 0.0;
+    a.hot_rdiag = 0.0;
+    if (hot_pattern >= 0 && hot_pattern < npat && h_hot_val && h_hot_val[4] != 0.0) {
+        a.hot = hot_pattern;
+        for (int k = 0; k < 9; ++k) a.hot_val[k] = h_hot_val[k];
+        a.hot_rdiag = 1.0 / h_hot_val[4];
+    }
+    hipStream_t st = lmg_stream(stream);
+    const bool resid = r_out != nullptr, zero = x_in == nullptr;
+    switch (union_mask) {
+    case kMask5: return launch1<kMask5>(a, sweeps, resid, zero, st);
+    case kMask9: return launch1<kMask9>(a, sweeps, resid, zero, st);
+    default: return LMG_ERR_CAPACITY;        // other slot sets: run the separate sweeps
+    }
+}
+
+int lmg_stencil_smooth_tiled_supported(uint32_t union_mask)
+{
+    return union_mask == kMask5 || union_mask == kMask9;
+}
+
+}  // extern "C"

@@ -15,6 +15,8 @@ int lmg_stencil_tune_set(const char *key, int v);
 int lmg_stencil_tune_get(const char *key);
 int lmg_fused_tune_set(const char *key, int v);
 int lmg_fused_tune_get(const char *key);
+int lmg_tile_tune_set(const char *key, int v);
+int lmg_tile_tune_get(const char *key);
 int lmg_gs_tune_set(int v);
 int lmg_gs_tune_get(void);
 
@@ -411,6 +413,7 @@ int lmg_tune_set(const char *key, int value)
     if (strcmp(key, "rpat_nt_rows") == 0) return lmg_rpat_nt_set(value);
     if (strncmp(key, "stencil_", 8) == 0) return lmg_stencil_tune_set(key, value);
     if (strncmp(key, "fused_", 6) == 0) return lmg_fused_tune_set(key, value);
+    if (strncmp(key, "tile_", 5) == 0) return lmg_tile_tune_set(key, value);
     if (strcmp(key, "gs_single_max") == 0) return lmg_gs_tune_set(value);
     return LMG_ERR_ARG;
 }
@@ -424,6 +427,7 @@ int lmg_tune_get(const char *key)
     if (strcmp(key, "rpat_nt_rows") == 0) return lmg_rpat_nt_get();
     if (strncmp(key, "stencil_", 8) == 0) return lmg_stencil_tune_get(key);
     if (strncmp(key, "fused_", 6) == 0) return lmg_fused_tune_get(key);
+    if (strncmp(key, "tile_", 5) == 0) return lmg_tile_tune_get(key);
     if (strcmp(key, "gs_single_max") == 0) return lmg_gs_tune_get();
     return LMG_ERR_ARG;
 }

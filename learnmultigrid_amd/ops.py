@@ -698,13 +698,34 @@ FUSED_MAX_SWEEPS = 3
 # the whole level is a few-microsecond kernel (measured: 1025^2 9-point, 3 sweeps + residual 63 us fused
 # vs ~30 us separate; 4097^2 5-point 198 us vs 310 us).
 FUSED_MIN_ROWS = 4_000_000
+# ... where the LDS-tiled pass (lmg_stencil_smooth_tiled: a workgroup per 64-column tile, all four waves on one sweep)
+# takes over, down to levels that are a handful of workgroups either way.
+TILED_MIN_ROWS = 4096
+_TILED_ENABLED = True
+
+
+def set_tiled_enabled(flag):
+    """Whether small grid-stencil levels run their sweeps as LDS-tiled fused passes (default) or one launch per
+    sweep (A/B runs and parity tests)."""
+    global _TILED_ENABLED
+    _TILED_ENABLED = bool(flag)
+
+
+def _fused_kind(A):
+    """'reg' (stencil_fused.hip), 'tile' (stencil_tile.hip) or None: how stencil_smooth would run on A."""
+    S = getattr(A, "stencil", None)
+    if not (_PACKED_ENABLED and _STENCIL_ENABLED and _FUSED_ENABLED and S is not None):
+        return None
+    if S.n >= FUSED_MIN_ROWS:
+        return "reg" if _lib.lib().lmg_stencil_smooth_supported(S.umask) else None
+    if _TILED_ENABLED and S.n >= TILED_MIN_ROWS and S.W >= 3 and _lib.lib().lmg_stencil_smooth_tiled_supported(S.umask):
+        return "tile"
+    return None
 
 
 def stencil_smooth_available(A):
-    """True when `A` has a grid-stencil twin, i.e. stencil_smooth can run its smoothing passes fused."""
-    S = getattr(A, "stencil", None)
-    return bool(_PACKED_ENABLED and _STENCIL_ENABLED and _FUSED_ENABLED and S is not None
-                and S.n >= FUSED_MIN_ROWS and _lib.lib().lmg_stencil_smooth_supported(S.umask))
+    """True when `A` has a grid-stencil twin whose smoothing passes stencil_smooth can run fused."""
+    return _fused_kind(A) is not None
 
 
 _FUSED_ENABLED = True
@@ -753,6 +774,11 @@ def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None, prolong=None, r
                                                     ctypes.addressof(T._hot_pairs), ctypes.addressof(T._hot_pval), _s()),
               "lmg_stencil_smooth_prolong")
         return
+    if _fused_kind(A) == "tile":
+        check(_lib.lib().lmg_stencil_smooth_tiled(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask, S.hot,
+                                                  hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out), _p(r_out), _s()),
+              "lmg_stencil_smooth_tiled")
+        return
     check(_lib.lib().lmg_stencil_smooth(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask, S.hot, hv,
                                         int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out), _p(r_out), _s()),
           "lmg_stencil_smooth")
@@ -778,7 +804,7 @@ def stencil_smooth_prolong_available(A, P):
     prolongation onto A's grid."""
     T = getattr(P, "prolong", None)
     S = getattr(A, "stencil", None)
-    return bool(_FUSED_PROLONG_ENABLED and T is not None and stencil_smooth_available(A) and T.n == S.n and T.W == S.W
+    return bool(_FUSED_PROLONG_ENABLED and T is not None and _fused_kind(A) == "reg" and T.n == S.n and T.W == S.W
                 and S.n >= FUSED_TRANSFER_MIN_ROWS and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask))
 
 
@@ -797,7 +823,7 @@ def stencil_smooth_restrict_available(A, R):
     restriction from A's grid with a coarse row under every (even line, even column) node."""
     T = getattr(R, "restrict", None)
     S = getattr(A, "stencil", None)
-    if not (_FUSED_RESTRICT_ENABLED and T is not None and stencil_smooth_available(A) and T.n == S.n and T.W == S.W
+    if not (_FUSED_RESTRICT_ENABLED and T is not None and _fused_kind(A) == "reg" and T.n == S.n and T.W == S.W
             and S.n >= FUSED_TRANSFER_MIN_ROWS and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask)):
         return False
     lines = (S.n + S.W - 1) // S.W

@@ -1044,19 +1044,32 @@ def test_row_pattern_sweeps_bit_exact(name, variant, nt):
 
 @pytest.mark.parametrize("name", ["poisson2d_129", "poisson1d", "galerkin_9pt", "with_empty_and_diagless_rows",
                                   "poisson2d_300"])
-@pytest.mark.parametrize("seg_lines,pf", [(0, 0), (4, 2), (7, 3), (1000, 2)])
+@pytest.mark.parametrize("seg_lines,pf", [(0, 0), (4, 2), (7, 3), (1000, 2), ("tile", 16), ("tile", 24), ("tile", 32)])
 def test_fused_stencil_smoothing_equals_separate_sweeps(name, seg_lines, pf):
-    """lmg_stencil_smooth (S sweeps [+ residual] in one pass, iterates in registers) against the oracle's
-    separate Jacobi sweeps and residual, bitwise, for S = 1..3, zero / non-zero initial iterate, with and
-    without the residual, few and many line segments per strip."""
+    """lmg_stencil_smooth (S sweeps [+ residual] in one pass, iterates in registers) and lmg_stencil_smooth_tiled
+    (the same with the iterates in LDS, what small levels run) against the oracle's separate Jacobi sweeps and
+    residual, bitwise, for S = 1..3, zero / non-zero initial iterate, with and without the residual, few and many
+    line segments per strip / 16-, 24- and 32-line tiles."""
     A = K.as_csr(P.poisson_2d_structured(299)[0]) if name == "poisson2d_300" else rpat_case(name)
     n = A.shape[0]
     dA = ops.DeviceCSR.from_scipy(A, DEV)
     dA.pack()
-    assert dA.stencil is not None and not ops.stencil_smooth_available(dA)        # small level: separate sweeps
+    assert dA.stencil is not None
+    tiled = seg_lines == "tile"
+    if tiled and not ops._lib.lib().lmg_stencil_smooth_tiled_supported(dA.stencil.umask):
+        pytest.skip("1-D chains run the register kernel")
     rng = np.random.default_rng(77)
     x0, b = rng.standard_normal(n), rng.standard_normal(n)
+    min_tiled = ops.TILED_MIN_ROWS
     try:
+        if tiled:
+            ops.TILED_MIN_ROWS = 0
+            ops.tune_set("tile_rows", pf)
+            assert ops._fused_kind(dA) == "tile"
+            seg_lines = pf = 0
+        else:
+            ops.set_tiled_enabled(False)                   # small level: the product would pick the tiled pass
+            assert ops._fused_kind(dA) is None
         ops.tune_set("fused_seg_lines", seg_lines)
         ops.tune_set("fused_pf", pf)
         for omega in (0.8, 1.0):
@@ -1078,6 +1091,9 @@ def test_fused_stencil_smoothing_equals_separate_sweeps(name, seg_lines, pf):
     finally:
         ops.tune_set("fused_seg_lines", 0)
         ops.tune_set("fused_pf", 0)
+        ops.tune_set("tile_rows", 0)
+        ops.set_tiled_enabled(True)
+        ops.TILED_MIN_ROWS = min_tiled
 
 
 @pytest.mark.parametrize("m,kind", [(64, "5pt"), (150, "5pt"), (64, "9pt"), (129, "9pt")])

@@ -189,21 +189,26 @@ def test_fused_smoothing_passes_equal_separate_sweeps(m, levels, steps):
     kw = dict(levels=levels, smoother="Jacobi", smooth_steps=steps, max_iterations=6, error=1e-30,
               smoother_semantics="as_named", omega=0.8)
     runs = {}
-    min_rows, min_tr = ops.FUSED_MIN_ROWS, ops.FUSED_TRANSFER_MIN_ROWS
+    min_rows, min_tr, min_tile = ops.FUSED_MIN_ROWS, ops.FUSED_TRANSFER_MIN_ROWS, ops.TILED_MIN_ROWS
     try:
-        ops.FUSED_MIN_ROWS = 0                       # (the product only fuses on multi-million-row levels)
-        ops.FUSED_TRANSFER_MIN_ROWS = 0
-        for fused in (False, True):
-            ops.set_fused_enabled(fused)
+        ops.TILED_MIN_ROWS = 0
+        for fused in (False, "reg", "tile"):
+            # "reg": the register-blocked passes (with the transfers folded in) on every level -- the product only
+            # uses them on multi-million-row levels; "tile": the product's choice at these sizes, LDS-tiled passes
+            ops.set_fused_enabled(bool(fused))
+            ops.FUSED_MIN_ROWS = 0 if fused == "reg" else min_rows
+            ops.FUSED_TRANSFER_MIN_ROWS = 0 if fused == "reg" else min_tr
             for graph in (False, True):
                 mg = HierarchyMG(A, rhs.copy(), hier)
                 mg.solve(use_graph=graph, **kw)
-                assert all(ops.stencil_smooth_available(lev.A) == fused for lev in mg._hier.levels[:-1])
+                kinds = [ops._fused_kind(lev.A) for lev in mg._hier.levels[:-1]]
+                assert kinds == [fused or None] * len(kinds), kinds
                 runs[fused, graph] = (mg.get_track_res(), mg.get_solution())
     finally:
         ops.set_fused_enabled(True)
         ops.FUSED_MIN_ROWS = min_rows
         ops.FUSED_TRANSFER_MIN_ROWS = min_tr
+        ops.TILED_MIN_ROWS = min_tile
     t0, x0 = runs[False, False]
     for key, (t, x) in runs.items():
         assert np.array_equal(t, t0) and np.array_equal(x, x0), key
@@ -365,7 +370,7 @@ def test_full_size_properties_4097():
     from learnmultigrid_amd import ops
     from oracle import kernels as K
     assert ops.stencil_smooth_available(mg._hier.levels[0].A)
-    assert not ops.stencil_smooth_available(mg._hier.levels[2].A)
+    assert [ops._fused_kind(lev.A) for lev in mg._hier.levels[:-1]] == ["reg", "reg", "tile", "tile", "tile"]
     try:
         ops.set_fused_enabled(False)
         mg3 = HierarchyMG(A, rhs.copy(), hier)

@@ -51,3 +51,11 @@ for side in (257, 513, 1025):
         ("prolongation+", chain_us(lambda: ops.csr_spmv(dP, xc, y, 1.0, 1.0))),
     ]
     print("%d^2: " % side + "   ".join("%s %.2f us" % kv for kv in res))
+    # the LDS-tiled fused passes of the same level (what the cycle launches): pre = 3 sweeps from zero + residual,
+    # post = 3 sweeps
+    for rows in (16, 24, 32):
+        ops.tune_set("tile_rows", rows)
+        pre = chain_us(lambda: ops.stencil_smooth(dA, None, b, 0.8, 3, y, r))
+        post = chain_us(lambda: ops.stencil_smooth(dA, x, b, 0.8, 3, y, None))
+        print("      tiled, %d-line tiles: pre-smoothing pass %.2f us   post-smoothing pass %.2f us" % (rows, pre, post))
+    ops.tune_set("tile_rows", 0)

@@ -693,13 +693,15 @@ def _stencil(mode, S, x, b, out, alpha, beta, partials, norm2):
 
 
 FUSED_MAX_SWEEPS = 3
-# Levels below this many rows run one launch per sweep: a fused pass walks its segment of lines
-# sequentially (>= 8 + 2 H dependent steps per wave), which costs more than the launches it saves once
-# the whole level is a few-microsecond kernel (measured: 1025^2 9-point, 3 sweeps + residual 63 us fused
-# vs ~30 us separate; 4097^2 5-point 198 us vs 310 us).
-FUSED_MIN_ROWS = 4_000_000
-# ... where the LDS-tiled pass (lmg_stencil_smooth_tiled: a workgroup per 64-column tile, all four waves on one sweep)
-# takes over, down to levels that are a handful of workgroups either way.
+# Two fused smoothing passes exist.  Levels beyond the Infinity Cache run the register-blocked pass of
+# stencil_fused.hip (a wave marches down a strip of lines with all iterates in registers: least traffic, but every
+# wave walks >= 12 lines one after the other); everything below runs the LDS-tiled pass of stencil_tile.hip (a
+# workgroup per 64 x 16 tile, four waves per sweep).  Measured (tools/time_mid.py, 3 sweeps + residual / 3 sweeps,
+# us): 9-point 2049^2 tile 71 / 54, register 97 / 61, separate 87 / 67; 5-point 2049^2 64 / 50, 67 / 44, 79 / 60;
+# 5-point 1449^2 37 / 28, 59 / 37, 46 / 35; 4097^2: register 166 / 125, separate 300 / 226.  In the cfg#4 cycle
+# the 2049^2 level on the tiled pass: 0.788 -> 0.766 ms.
+FUSED_MIN_ROWS = 8_000_000
+# The tiled pass takes over below, down to levels that are a handful of workgroups either way.
 TILED_MIN_ROWS = 4096
 _TILED_ENABLED = True
 

@@ -370,7 +370,7 @@ def test_full_size_properties_4097():
     from learnmultigrid_amd import ops
     from oracle import kernels as K
     assert ops.stencil_smooth_available(mg._hier.levels[0].A)
-    assert [ops._fused_kind(lev.A) for lev in mg._hier.levels[:-1]] == ["reg", "reg", "tile", "tile", "tile"]
+    assert [ops._fused_kind(lev.A) for lev in mg._hier.levels[:-1]] == ["reg", "tile", "tile", "tile", "tile"]
     try:
         ops.set_fused_enabled(False)
         mg3 = HierarchyMG(A, rhs.copy(), hier)

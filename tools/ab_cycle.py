@@ -4,12 +4,13 @@ V(3,3) cycle once per setting and times the replays round-robin (a stand-alone t
 gpurun box have both pointed the wrong way before; see csrc/stencil_fused.hip).
 
   python tools/ab_cycle.py --set base --set fused_pf=3 --set fused_seg_lines=24 --set py:FUSED_MIN_ROWS=1000000
-Settings: `key=value[,key=value...]` for ops.tune_set keys, `py:NAME=value` for module constants of ops.
+Settings: `key=value[,key=value...]` for ops.tune_set keys, `py:NAME=value` / `coarse:NAME=value` for module
+constants of ops / coarse.
 """
 import argparse, ast, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from learnmultigrid_amd import ops, problems as P
+from learnmultigrid_amd import coarse, ops, problems as P
 from learnmultigrid_amd.hierarchy import Hierarchy
 
 ap = argparse.ArgumentParser()
@@ -37,10 +38,10 @@ def apply(setting, undo=False):
         return saved
     for kv in setting.split(","):
         k, v = kv.split("=")
-        if k.startswith("py:"):
-            name = k[3:]
-            saved.append((k, getattr(ops, name)))
-            setattr(ops, name, ast.literal_eval(v))
+        if k.startswith("py:") or k.startswith("coarse:"):
+            mod, name = (ops, k[3:]) if k.startswith("py:") else (coarse, k[7:])
+            saved.append((k, getattr(mod, name)))
+            setattr(mod, name, ast.literal_eval(v))
         else:
             saved.append((k, ops.tune_get(k)))
             ops.tune_set(k, int(v))
@@ -49,7 +50,9 @@ def apply(setting, undo=False):
 
 def restore(saved):
     for k, v in saved:
-        if k.startswith("py:"):
+        if k.startswith("coarse:"):
+            setattr(coarse, k[7:], v)
+        elif k.startswith("py:"):
             setattr(ops, k[3:], v)
         else:
             ops.tune_set(k, v)

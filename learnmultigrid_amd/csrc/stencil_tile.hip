@@ -57,10 +57,10 @@ template <int S, unsigned UM, bool RESID, bool ZERO, int RR>
 __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
 {
     constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);
-    static_assert(RR > 2 * H + 1 && kCols > 2 * H, "tile smaller than its halo");
+    static_assert(RR > 2 * H + 1 && kCols > 2 * H && RR % kWaves == 0, "tile smaller than its halo / lines per wave");
+    // LDS holds the two iterate buffers only: right-hand side and pattern ids of a wave's own lines never change and
+    // stay in its registers (32-line tiles: 39 KB instead of 60, i.e. four workgroups per CU instead of two).
     __shared__ double s_x[2][RR * kLS];
-    __shared__ double s_b[RR * kLS];
-    __shared__ unsigned short s_p[RR * kCols];             // pattern id | 0x100 where the element is a row of the matrix
     __shared__ double s_val[kMaxPat * 9];
     __shared__ int s_mask[kMaxPat];
     __shared__ double s_rdiag[kMaxPat];
@@ -70,21 +70,22 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
     const int c0 = tx * (kCols - 2 * H) - H, y0 = ty * (RR - 2 * H) - H;
     const int n = a.n;
     const int64_t W = a.W;
+    constexpr int RB = RR / kWaves;                              // consecutive lines of the tile a wave owns
+    constexpr bool DIAG = (UM & 0x145u) != 0;
+    const int rb0 = wave * RB;
 
-    // ---- the tile's lines are requested first, the pattern table is staged while they are in flight ----------
-    constexpr int kPer = (RR + kWaves - 1) / kWaves;
-    double lx[kPer], lb[kPer];
-    int lp[kPer];
+    // ---- the wave's lines are requested first, the pattern table is staged while they are in flight -------------
+    double lx[RB], bk[RB];
+    int pk[RB];                                                   // pattern id | 0x100 where the element is a row of the matrix
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-        const int r = wave + k * kWaves;
-        const int y = y0 + r;
+    for (int k = 0; k < RB; ++k) {
+        const int y = y0 + rb0 + k;
         const int64_t i = (int64_t)y * W + c0 + lane;
-        const bool ok = r < RR && y >= 0 && y < a.lines && i >= 0 && i < n;
+        const bool ok = y >= 0 && y < a.lines && i >= 0 && i < n;
         const int64_t j = ok ? i : 0;
         lx[k] = (!ZERO && ok) ? a.x[j] : 0.0;
-        lb[k] = ok ? a.b[j] : 0.0;
-        lp[k] = ok ? ((int)a.pid[j] | 0x100) : 0;
+        bk[k] = ok ? a.b[j] : 0.0;
+        pk[k] = ok ? ((int)a.pid[j] | 0x100) : 0;
     }
     for (int i = t; i < a.npat * 9; i += kBlock) s_val[i] = a.st_val[i];
     for (int i = t; i < a.npat; i += kBlock) {
@@ -98,33 +99,27 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
         s_x[0][r * kLS + g] = 0.0;
         s_x[1][r * kLS + g] = 0.0;
     }
+    const int hot = a.hot >= 0 ? (a.hot | 0x100) : -1;
+    bool mine = true;
 #pragma unroll
-    for (int k = 0; k < kPer; ++k) {
-        const int r = wave + k * kWaves;
-        if (r < RR) {
-            s_x[0][r * kLS + 1 + lane] = lx[k];
-            s_x[1][r * kLS + 1 + lane] = 0.0;
-            s_b[r * kLS + 1 + lane] = lb[k];
-            s_p[r * kCols + lane] = (unsigned short)lp[k];
-        }
+    for (int k = 0; k < RB; ++k) {
+        s_x[0][(rb0 + k) * kLS + 1 + lane] = lx[k];
+        s_x[1][(rb0 + k) * kLS + 1 + lane] = 0.0;
+        mine = mine && (pk[k] == hot || !(pk[k] >> 8));          // (elements outside the matrix are not stored)
     }
+    // every lane of every line of this wave holds the frequent pattern: its values sit in scalar registers
+    const bool all_hot = __all(mine);
     __syncthreads();
 
     const double omega = a.omega;
-    const int hot = a.hot >= 0 ? (a.hot | 0x100) : -1;
     double hv[9];
 #pragma unroll
     for (int s = 0; s < 9; ++s) hv[s] = a.hot_val[s];
     const double hrd = a.hot_rdiag;
 
-    // Each wave owns RB consecutive lines of the tile and slides a three-line window down them: the centre values
-    // of a new line come from LDS (one 8-byte read per lane), its left / right neighbours from the neighbouring
-    // lanes (DPP; lanes 0 / 63 get the zero of the guard columns -- they are halo), so a line costs one LDS read of
-    // x instead of nine.
-    constexpr int RB = RR / kWaves;
-    static_assert(RR % kWaves == 0, "lines per wave");
-    constexpr bool DIAG = (UM & 0x145u) != 0;
-    const int rb0 = wave * RB;
+    // A wave slides a three-line window down its lines: the centre values of a line come from LDS (one 8-byte read
+    // per lane), its left / right neighbours from the neighbouring lanes (DPP; lanes 0 / 63 get the zero of the
+    // guard columns -- they are halo), so a line costs one LDS read instead of nine.
     struct Win { double m, c, p; };
     auto line = [&](const double *src, int r, bool sides) -> Win {
         Win w;
@@ -134,10 +129,10 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
         return w;
     };
     // A x of the centre line of (u, c, d) for this lane, slot order = column order
-    auto apply = [&](const Win &u, const Win &c, const Win &d, int p, bool all_hot) -> double {
+    auto apply = [&](const Win &u, const Win &c, const Win &d, int p, bool hotp) -> double {
         const double w[9] = {u.m, u.c, u.p, c.m, c.c, c.p, d.m, d.c, d.p};
         double acc = 0.0;
-        if (all_hot) {
+        if (hotp) {
 #pragma unroll
             for (int s = 0; s < 9; ++s)
                 if ((UM >> s) & 1u) acc = acc + hv[s] * w[s];
@@ -152,11 +147,10 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
         }
         return acc;
     };
-
-    // One block of RB lines, straight-line: all its lines are read first, then either every lane of every line holds
-    // the frequent pattern (values in scalar registers) or every line goes through the pattern table -- no branch
-    // inside either path, so the LDS latencies and the dependent sums of the RB lines overlap.  Lines outside
-    // [lo, hi) are computed from clamped (meaningless) neighbours and not stored.
+    // The wave's block of RB lines, straight-line: all its lines are read first, then either the frequent pattern
+    // everywhere or every line through the pattern table -- no branch inside either path, so the LDS latencies and
+    // the dependent sums of the RB lines overlap.  Lines outside [lo, hi) are computed from clamped (meaningless)
+    // neighbours and not kept.
     auto block = [&](const double *src, int lo, int hi, auto &&emit) {
         Win ln[RB + 2];
 #pragma unroll
@@ -164,26 +158,17 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
             const int rr = min(max(rb0 - 1 + j, 0), RR - 1);
             ln[j] = line(src, rr, DIAG || (j >= 1 && j <= RB));
         }
-        int pk[RB];
-        double bk[RB];
-        bool mine = true;
-#pragma unroll
-        for (int k = 0; k < RB; ++k) {
-            pk[k] = s_p[(rb0 + k) * kCols + lane];
-            bk[k] = s_b[(rb0 + k) * kLS + 1 + lane];
-            mine = mine && (pk[k] == hot || !(pk[k] >> 8));      // (elements outside the matrix are not stored)
-        }
-        if (__all(mine)) {                                         // wave-uniform
+        if (all_hot) {                                             // wave-uniform
 #pragma unroll
             for (int k = 0; k < RB; ++k) {
                 const double acc = apply(ln[k], ln[k + 1], ln[k + 2], pk[k], true);
-                emit(rb0 + k, rb0 + k >= lo && rb0 + k < hi, pk[k], true, ln[k + 1].c, bk[k], acc);
+                emit(k, rb0 + k >= lo && rb0 + k < hi, true, ln[k + 1].c, acc);
             }
         } else {
 #pragma unroll
             for (int k = 0; k < RB; ++k) {
                 const double acc = apply(ln[k], ln[k + 1], ln[k + 2], pk[k], false);
-                emit(rb0 + k, rb0 + k >= lo && rb0 + k < hi, pk[k], false, ln[k + 1].c, bk[k], acc);
+                emit(k, rb0 + k >= lo && rb0 + k < hi, false, ln[k + 1].c, acc);
             }
         }
     };
@@ -196,24 +181,20 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
         if (ZERO && s == 1) {
             // first sweep from a zero iterate: x = omega * (D^-1 b) on every line (lmg_vmul's bits)
 #pragma unroll
-            for (int k = 0; k < RB; ++k) {
-                const int r = rb0 + k;
-                const int p = s_p[r * kCols + lane];
-                const double bv = s_b[r * kLS + 1 + lane];
-                dst[r * kLS + 1 + lane] = (p >> 8) ? omega * (s_rdiag[p & 0xff] * bv) : 0.0;
-            }
+            for (int k = 0; k < RB; ++k)
+                dst[(rb0 + k) * kLS + 1 + lane] = (pk[k] >> 8) ? omega * (s_rdiag[pk[k] & 0xff] * bk[k]) : 0.0;
         } else {
             // (lines 0 and RR - 1 have no line above / below)
-            block(src, 1, RR - 1, [&](int r, bool keep, int p, bool all_hot, double xc, double bv, double acc) {
-                const double res = bv - acc;
+            block(src, 1, RR - 1, [&](int k, bool keep, bool hotp, double xc, double acc) {
+                const double res = bk[k] - acc;
                 double nx;
-                if (all_hot) {
+                if (hotp) {
                     nx = xc + omega * (hrd * res);
                 } else {
-                    const int q = p & 0xff;
+                    const int q = pk[k] & 0xff;
                     nx = (s_mask[q] >> 16) ? xc : xc + omega * (s_rdiag[q] * res);
                 }
-                if (keep) dst[r * kLS + 1 + lane] = (p >> 8) ? nx : 0.0;
+                if (keep) dst[(rb0 + k) * kLS + 1 + lane] = (pk[k] >> 8) ? nx : 0.0;
             });
         }
         __syncthreads();
@@ -223,27 +204,26 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
     const double *fin = s_x[S & 1];
     const bool col_ok = lane >= H && lane < kCols - H && c0 + lane >= 0 && c0 + lane < W;
     if (RESID) {
-        block(fin, H, RR - H, [&](int r, bool keep, int p, bool, double xc, double bv, double acc) {
-            const int64_t i = (int64_t)(y0 + r) * W + c0 + lane;
-            if (keep && col_ok && (p >> 8)) {
+        block(fin, H, RR - H, [&](int k, bool keep, bool, double xc, double acc) {
+            const int64_t i = (int64_t)(y0 + rb0 + k) * W + c0 + lane;
+            if (keep && col_ok && (pk[k] >> 8)) {
                 a.out[i] = xc;
-                a.r[i] = bv - acc;
+                a.r[i] = bk[k] - acc;
             }
         });
     } else {
 #pragma unroll
         for (int k = 0; k < RB; ++k) {
             const int r = rb0 + k;
-            if (r >= H && r < RR - H) {
-                const int p = s_p[r * kCols + lane];
-                const int64_t i = (int64_t)(y0 + r) * W + c0 + lane;
-                if (col_ok && (p >> 8)) a.out[i] = fin[r * kLS + 1 + lane];
-            }
+            if (r >= H && r < RR - H && col_ok && (pk[k] >> 8))
+                a.out[(int64_t)(y0 + r) * W + c0 + lane] = fin[r * kLS + 1 + lane];
         }
     }
 }
 
 int g_tile_rows = 0;        // 0 = chosen per launch (tuning: 16, 24, 32)
+int g_tile_rows_big = 0;    // the same for grids of at least g_tile_big_lines lines (tuning one level of a cycle)
+int g_tile_big_lines = 0x7fffffff;
 
 template <int S, unsigned UM, bool RESID, bool ZERO, int RR>
 int launch5(TArgs a, hipStream_t st)
@@ -261,7 +241,7 @@ int launch5(TArgs a, hipStream_t st)
 template <int S, unsigned UM, bool RESID, bool ZERO>
 int launch4(TArgs a, hipStream_t st)
 {
-    int rr = g_tile_rows;
+    int rr = a.lines >= g_tile_big_lines ? g_tile_rows_big : g_tile_rows;
     if (rr == 0) rr = 16;         // measured in the cycle (cfg#4): 0.780 ms with 16-line tiles, 0.795 with 24, 0.814 with 32
     switch (rr) {
     case 16: return launch5<S, UM, RESID, ZERO, 16>(a, st);
@@ -291,9 +271,14 @@ int launch1(TArgs a, int sweeps, bool resid, bool zero, hipStream_t st)
 
 int lmg_tile_tune_set(const char *key, int v)
 {
-    if (strcmp(key, "tile_rows") == 0) {
+    if (strcmp(key, "tile_rows") == 0 || strcmp(key, "tile_rows_big") == 0) {
         if (v != 0 && v != 16 && v != 24 && v != 32) return LMG_ERR_ARG;
-        g_tile_rows = v;
+        (key[9] ? g_tile_rows_big : g_tile_rows) = v;
+        return LMG_OK;
+    }
+    if (strcmp(key, "tile_big_lines") == 0) {
+        if (v < 0) return LMG_ERR_ARG;
+        g_tile_big_lines = v;
         return LMG_OK;
     }
     return LMG_ERR_ARG;
@@ -301,6 +286,8 @@ int lmg_tile_tune_set(const char *key, int v)
 int lmg_tile_tune_get(const char *key)
 {
     if (strcmp(key, "tile_rows") == 0) return g_tile_rows;
+    if (strcmp(key, "tile_rows_big") == 0) return g_tile_rows_big;
+    if (strcmp(key, "tile_big_lines") == 0) return g_tile_big_lines;
     return LMG_ERR_ARG;
 }
 

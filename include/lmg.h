@@ -199,6 +199,15 @@ int lmg_stencil_smooth_tiled(int64_t n, int32_t line_stride, const uint8_t *d_pi
                              const double *d_st_val, const int32_t *d_st_mask, uint32_t union_mask,
                              int32_t hot_pattern, const double *h_hot_val, int sweeps, const double *d_x_in,
                              const double *d_b, double omega, double *d_x_out, double *d_r_out, void *stream);
+/* ... and with the coarse-grid correction folded in, x_out = J^sweeps(x_in + P e_coarse): the tile is loaded as
+ * x + P e (row patterns of P as in lmg_stencil_smooth_prolong, no frequent-pair shortcut needed: the correction is
+ * formed once per element, with the sums of lmg_rpat_sweep_grid(SPMV, alpha = 1, beta = 1) in order). */
+int lmg_stencil_smooth_tiled_prolong(int64_t n, int32_t line_stride, const uint8_t *d_pid, int32_t npat,
+                                     const double *d_st_val, const int32_t *d_st_mask, uint32_t union_mask,
+                                     int32_t hot_pattern, const double *h_hot_val, int sweeps, const double *d_x_in,
+                                     const double *d_b, double omega, double *d_x_out, int64_t n_coarse,
+                                     int32_t coarse_stride, const double *d_e_coarse, const uint8_t *d_p_pid,
+                                     int32_t p_npat, const double *d_p_val, const int32_t *d_p_mask, void *stream);
 
 /* The same pass with the coarse-grid correction folded in (Multigrid.py:115 + :121 in one pass):
  *     x_out = J^sweeps(x_in + P e_coarse)

@@ -51,11 +51,20 @@ struct TArgs {
     int hot;
     double hot_val[9];
     double hot_rdiag;
+    // PROL: the sweeps start from x + P e_c (Multigrid.py:115 folded into the post-smoothing pass), formed when the tile
+    // is loaded: row i = y * W + x of P reads e_c at ((y >> 1) * Wc + (x >> 1)) + {0, 1, Wc, Wc + 1} (slots 0..3)
+    const double *ec;
+    int nc, Wc;
+    const unsigned char *ppid;
+    const double *pp_val;     // [pp_npat][4]
+    const int *pp_mask;       // [pp_npat]
+    int pp_npat;
 };
 
-template <int S, unsigned UM, bool RESID, bool ZERO, int RR>
+template <int S, unsigned UM, bool RESID, bool ZERO, int RR, bool PROL = false>
 __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
 {
+    static_assert(!PROL || (!RESID && !ZERO), "the correction is folded into post-smoothing passes only");
     constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);
     static_assert(RR > 2 * H + 1 && kCols > 2 * H && RR % kWaves == 0, "tile smaller than its halo / lines per wave");
     // LDS holds the two iterate buffers only: right-hand side and pattern ids of a wave's own lines never change and
@@ -64,6 +73,8 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
     __shared__ double s_val[kMaxPat * 9];
     __shared__ int s_mask[kMaxPat];
     __shared__ double s_rdiag[kMaxPat];
+    __shared__ double s_pv[PROL ? kMaxPat * 4 : 1];
+    __shared__ int s_pm[PROL ? kMaxPat : 1];
 
     const int t = threadIdx.x, lane = t & (LMG_WAVE - 1), wave = t >> 6;
     const int tx = (int)blockIdx.x % a.tiles_x, ty = (int)blockIdx.x / a.tiles_x;
@@ -77,6 +88,8 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
     // ---- the wave's lines are requested first, the pattern table is staged while they are in flight -------------
     double lx[RB], bk[RB];
     int pk[RB];                                                   // pattern id | 0x100 where the element is a row of the matrix
+    double le[PROL ? RB : 1][4];                                  // PROL: the 2 x 2 coarse window of every element
+    int lq[PROL ? RB : 1];                                        //       and its pattern id in P
 #pragma unroll
     for (int k = 0; k < RB; ++k) {
         const int y = y0 + rb0 + k;
@@ -86,6 +99,18 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
         lx[k] = (!ZERO && ok) ? a.x[j] : 0.0;
         bk[k] = ok ? a.b[j] : 0.0;
         pk[k] = ok ? ((int)a.pid[j] | 0x100) : 0;
+        if (PROL) {
+            // the element is row j of P whatever its place in the tile (a column outside [0, W) is an element of the
+            // adjacent line): its own line and column decide the window
+            const unsigned yy = (unsigned)j / (unsigned)a.W, xx = (unsigned)j - yy * (unsigned)a.W;
+            const int64_t base = (int64_t)(yy >> 1) * a.Wc + (xx >> 1);
+            lq[k] = ok ? (int)a.ppid[j] : 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t jc = base + (q & 1) + (q >> 1) * (int64_t)a.Wc;
+                le[k][q] = a.ec[jc < a.nc ? jc : a.nc - 1];       // (slots a pattern does not have may point anywhere)
+            }
+        }
     }
     for (int i = t; i < a.npat * 9; i += kBlock) s_val[i] = a.st_val[i];
     for (int i = t; i < a.npat; i += kBlock) {
@@ -98,6 +123,23 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
         const int r = i >> 1, g = (i & 1) ? kLS - 1 : 0;
         s_x[0][r * kLS + g] = 0.0;
         s_x[1][r * kLS + g] = 0.0;
+    }
+    if (PROL) {
+        for (int i = t; i < a.pp_npat * 4; i += kBlock) s_pv[i] = a.pp_val[i];
+        for (int i = t; i < a.pp_npat; i += kBlock) s_pm[i] = a.pp_mask[i];
+        __syncthreads();
+        // x + P e: the sums of lmg_rpat_sweep_grid(SPMV, alpha = 1, beta = 1) in the same order
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            const int m = s_pm[lq[k]];
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double tv = acc + s_pv[lq[k] * 4 + q] * le[k][q];
+                acc = ((m >> q) & 1) ? tv : acc;
+            }
+            lx[k] = (pk[k] >> 8) ? lx[k] + acc : 0.0;
+        }
     }
     const int hot = a.hot >= 0 ? (a.hot | 0x100) : -1;
     bool mine = true;
@@ -225,7 +267,7 @@ int g_tile_rows = 0;        // 0 = chosen per launch (tuning: 16, 24, 32)
 int g_tile_rows_big = 0;    // the same for grids of at least g_tile_big_lines lines (tuning one level of a cycle)
 int g_tile_big_lines = 0x7fffffff;
 
-template <int S, unsigned UM, bool RESID, bool ZERO, int RR>
+template <int S, unsigned UM, bool RESID, bool ZERO, int RR, bool PROL = false>
 int launch5(TArgs a, hipStream_t st)
 {
     constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);
@@ -233,7 +275,7 @@ int launch5(TArgs a, hipStream_t st)
     a.tiles_y = (a.lines + (RR - 2 * H) - 1) / (RR - 2 * H);
     const int64_t grid = (int64_t)a.tiles_x * a.tiles_y;
     if (grid > 0x7fffffff) return LMG_ERR_CAPACITY;
-    hipLaunchKernelGGL((stencil_tile_kernel<S, UM, RESID, ZERO, RR>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((stencil_tile_kernel<S, UM, RESID, ZERO, RR, PROL>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }
@@ -247,6 +289,17 @@ int launch4(TArgs a, hipStream_t st)
     case 16: return launch5<S, UM, RESID, ZERO, 16>(a, st);
     case 24: return launch5<S, UM, RESID, ZERO, 24>(a, st);
     default: return launch5<S, UM, RESID, ZERO, 32>(a, st);
+    }
+}
+
+template <unsigned UM>
+int launch_prol(TArgs a, int sweeps, hipStream_t st)
+{
+    // (16-line tiles: measured best at every size)
+    switch (sweeps) {
+    case 1: return launch5<1, UM, false, false, 16, true>(a, st);
+    case 2: return launch5<2, UM, false, false, 16, true>(a, st);
+    default: return launch5<3, UM, false, false, 16, true>(a, st);
     }
 }
 
@@ -293,10 +346,9 @@ int lmg_tile_tune_get(const char *key)
 
 extern "C" {
 
-int lmg_stencil_smooth_tiled(int64_t n, int32_t line_stride, const uint8_t *pid, int32_t npat, const double *st_val,
-                             const int32_t *st_mask, uint32_t union_mask, int32_t hot_pattern, const double *h_hot_val,
-                             int sweeps, const double *x_in, const double *b, double omega, double *x_out, double *r_out,
-                             void *stream)
+static int tile_args(TArgs &a, int64_t n, int32_t line_stride, const uint8_t *pid, int32_t npat, const double *st_val,
+                     const int32_t *st_mask, uint32_t union_mask, int32_t hot_pattern, const double *h_hot_val, int sweeps,
+                     const double *x_in, const double *b, double omega, double *x_out, double *r_out)
 {
     if (n < 0 || n >= (1ll << 31) - 4096 || npat < 1 || npat > kMaxPat || (union_mask & ~0x1FFu)) return LMG_ERR_ARG;
     if (sweeps < 1 || sweeps > 3) return LMG_ERR_ARG;
@@ -304,7 +356,6 @@ int lmg_stencil_smooth_tiled(int64_t n, int32_t line_stride, const uint8_t *pid,
     if (!pid || !st_val || !st_mask || !b || !x_out || x_in == x_out || r_out == x_out || (r_out && r_out == x_in))
         return LMG_ERR_ARG;
     if (line_stride < 3 || line_stride > n) return LMG_ERR_ARG;
-    TArgs a;
     a.n = (int)n;
     a.W = line_stride;
     a.lines = (int)((n + line_stride - 1) / line_stride);
@@ -326,12 +377,59 @@ int lmg_stencil_smooth_tiled(int64_t n, int32_t line_stride, const uint8_t *pid,
         for (int k = 0; k < 9; ++k) a.hot_val[k] = h_hot_val[k];
         a.hot_rdiag = 1.0 / h_hot_val[4];
     }
+    a.ec = nullptr;
+    a.nc = a.Wc = 0;
+    a.ppid = nullptr;
+    a.pp_val = nullptr;
+    a.pp_mask = nullptr;
+    a.pp_npat = 0;
+    return 1;                                  // filled: launch
+}
+
+int lmg_stencil_smooth_tiled(int64_t n, int32_t line_stride, const uint8_t *pid, int32_t npat, const double *st_val,
+                             const int32_t *st_mask, uint32_t union_mask, int32_t hot_pattern, const double *h_hot_val,
+                             int sweeps, const double *x_in, const double *b, double omega, double *x_out, double *r_out,
+                             void *stream)
+{
+    TArgs a;
+    const int rc = tile_args(a, n, line_stride, pid, npat, st_val, st_mask, union_mask, hot_pattern, h_hot_val, sweeps, x_in, b,
+                             omega, x_out, r_out);
+    if (rc != 1) return rc;
     hipStream_t st = lmg_stream(stream);
     const bool resid = r_out != nullptr, zero = x_in == nullptr;
     switch (union_mask) {
     case kMask5: return launch1<kMask5>(a, sweeps, resid, zero, st);
     case kMask9: return launch1<kMask9>(a, sweeps, resid, zero, st);
     default: return LMG_ERR_CAPACITY;        // other slot sets: run the separate sweeps
+    }
+}
+
+int lmg_stencil_smooth_tiled_prolong(int64_t n, int32_t line_stride, const uint8_t *pid, int32_t npat, const double *st_val,
+                                     const int32_t *st_mask, uint32_t union_mask, int32_t hot_pattern,
+                                     const double *h_hot_val, int sweeps, const double *x_in, const double *b, double omega,
+                                     double *x_out, int64_t n_coarse, int32_t coarse_stride, const double *e_coarse,
+                                     const uint8_t *p_pid, int32_t p_npat, const double *p_val, const int32_t *p_mask,
+                                     void *stream)
+{
+    if (!x_in || !e_coarse || !p_pid || !p_val || !p_mask || p_npat < 1 || p_npat > kMaxPat) return LMG_ERR_ARG;
+    if (n_coarse < 1 || n_coarse >= (1ll << 31) || coarse_stride < 1 || coarse_stride > n_coarse) return LMG_ERR_ARG;
+    if (e_coarse == x_out) return LMG_ERR_ARG;
+    TArgs a;
+    const int rc = tile_args(a, n, line_stride, pid, npat, st_val, st_mask, union_mask, hot_pattern, h_hot_val, sweeps, x_in, b,
+                             omega, x_out, nullptr);
+    if (rc != 1) return rc;
+    a.ec = e_coarse;
+    a.nc = (int)n_coarse;
+    a.Wc = coarse_stride;
+    a.ppid = p_pid;
+    a.pp_val = p_val;
+    a.pp_mask = p_mask;
+    a.pp_npat = p_npat;
+    hipStream_t st = lmg_stream(stream);
+    switch (union_mask) {
+    case kMask5: return launch_prol<kMask5>(a, sweeps, st);
+    case kMask9: return launch_prol<kMask9>(a, sweeps, st);
+    default: return LMG_ERR_CAPACITY;
     }
 }
 

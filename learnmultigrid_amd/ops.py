@@ -770,6 +770,12 @@ def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None, prolong=None, r
         _vec_ok(e)
         if T is None or r_out is not None or x_in is None or T.n != S.n or T.W != S.W or e.numel() != T.nc:
             raise LmgError("stencil_smooth: this prolongation cannot be fused into the pass")
+        if _fused_kind(A) == "tile":
+            check(_lib.lib().lmg_stencil_smooth_tiled_prolong(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask,
+                                                              S.hot, hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out),
+                                                              T.nc, T.Wc, _p(e), _p(T.pid), T.npat, _p(T.p_val), _p(T.p_mask),
+                                                              _s()), "lmg_stencil_smooth_tiled_prolong")
+            return
         check(_lib.lib().lmg_stencil_smooth_prolong(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask, S.hot,
                                                     hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out), T.nc, T.Wc,
                                                     _p(e), _p(T.pid), T.npat, _p(T.p_val), _p(T.p_mask),
@@ -806,8 +812,12 @@ def stencil_smooth_prolong_available(A, P):
     prolongation onto A's grid."""
     T = getattr(P, "prolong", None)
     S = getattr(A, "stencil", None)
-    return bool(_FUSED_PROLONG_ENABLED and T is not None and _fused_kind(A) == "reg" and T.n == S.n and T.W == S.W
-                and S.n >= FUSED_TRANSFER_MIN_ROWS and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask))
+    kind = _fused_kind(A)
+    if not (_FUSED_PROLONG_ENABLED and T is not None and kind is not None and T.n == S.n and T.W == S.W):
+        return False
+    if kind == "tile":                   # the tile is loaded as x + P e: always cheaper than the P launch it replaces
+        return True
+    return bool(S.n >= FUSED_TRANSFER_MIN_ROWS and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask))
 
 
 _FUSED_RESTRICT_ENABLED = True

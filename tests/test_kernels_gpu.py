@@ -1097,12 +1097,13 @@ def test_fused_stencil_smoothing_equals_separate_sweeps(name, seg_lines, pf):
 
 
 @pytest.mark.parametrize("m,kind", [(64, "5pt"), (150, "5pt"), (64, "9pt"), (129, "9pt")])
-@pytest.mark.parametrize("seg_lines", [0, 5, 1000])
+@pytest.mark.parametrize("seg_lines", [0, 5, 1000, "tile"])
 def test_fused_post_smoothing_with_the_correction_folded_in(m, kind, seg_lines):
-    """lmg_stencil_smooth_prolong: x_out = J^S(x + P e) in one pass, against the oracle's prolongation
-    (K.spmv alpha = beta = 1) followed by S separate Jacobi sweeps, bitwise; 5-point fine operators and
-    9-point Galerkin operators, tensor-product interpolation between (2m+1)^2 and (m+1)^2 nodes, strips /
-    segments that start on odd and even lines and columns."""
+    """lmg_stencil_smooth_prolong / lmg_stencil_smooth_tiled_prolong: x_out = J^S(x + P e) in one pass, against the
+    oracle's prolongation (K.spmv alpha = beta = 1) followed by S separate Jacobi sweeps, bitwise; 5-point fine
+    operators and 9-point Galerkin operators, tensor-product interpolation between (2m+1)^2 and (m+1)^2 nodes,
+    strips / segments that start on odd and even lines and columns; the LDS-tiled pass ("tile": what these sizes
+    run in the product) and the register-blocked one."""
     side = 2 * m + 1
     if kind == "5pt":
         A = K.as_csr(P.poisson_2d_structured(side - 1)[0])
@@ -1122,7 +1123,14 @@ def test_fused_post_smoothing_with_the_correction_folded_in(m, kind, seg_lines):
     assert T._hot_pairs[0] >= 0 and T._hot_pairs[1] >= 0
     rng = np.random.default_rng(5)
     x0, b, e = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(nc)
+    tiled = seg_lines == "tile"
     try:
+        if tiled:
+            seg_lines = 0
+            assert ops._fused_kind(dA) == "tile" and ops.stencil_smooth_prolong_available(dA, dP)
+        else:
+            ops.set_tiled_enabled(False)
+            assert ops._fused_kind(dA) is None
         ops.tune_set("fused_seg_lines", seg_lines)
         for omega in (0.8, 1.0):
             want = K.spmv(Pm, e, x0.copy(), 1.0, 1.0)
@@ -1142,6 +1150,7 @@ def test_fused_post_smoothing_with_the_correction_folded_in(m, kind, seg_lines):
         assert np.array_equal(out.cpu().numpy(), want)
     finally:
         ops.tune_set("fused_seg_lines", 0)
+        ops.set_tiled_enabled(True)
 
 
 @pytest.mark.parametrize("m,kind", [(64, "5pt"), (150, "5pt"), (64, "9pt"), (129, "9pt")])

@@ -208,6 +208,15 @@ int lmg_stencil_smooth_tiled_prolong(int64_t n, int32_t line_stride, const uint8
                                      const double *d_b, double omega, double *d_x_out, int64_t n_coarse,
                                      int32_t coarse_stride, const double *d_e_coarse, const uint8_t *d_p_pid,
                                      int32_t p_npat, const double *d_p_val, const int32_t *d_p_mask, void *stream);
+/* ... and with the restriction folded in, b_coarse = R (b - A x_out) instead of the residual (arguments of
+ * lmg_stencil_smooth_restrict without the frequent-pattern shortcut): the residual of the tile goes to LDS, every
+ * element on an (even line, even column) node sums the nine entries of its row of R in column order. */
+int lmg_stencil_smooth_tiled_restrict(int64_t n, int32_t line_stride, const uint8_t *d_pid, int32_t npat,
+                                      const double *d_st_val, const int32_t *d_st_mask, uint32_t union_mask,
+                                      int32_t hot_pattern, const double *h_hot_val, int sweeps, const double *d_x_in,
+                                      const double *d_b, double omega, double *d_x_out, int64_t n_coarse,
+                                      int32_t coarse_stride, double *d_b_coarse, const uint8_t *d_r_pid,
+                                      int32_t r_npat, const double *d_r_val, const int32_t *d_r_mask, void *stream);
 
 /* The same pass with the coarse-grid correction folded in (Multigrid.py:115 + :121 in one pass):
  *     x_out = J^sweeps(x_in + P e_coarse)

@@ -59,13 +59,22 @@ struct TArgs {
     const double *pp_val;     // [pp_npat][4]
     const int *pp_mask;       // [pp_npat]
     int pp_npat;
+    // REST: b_coarse = R (b - A x_out) instead of the residual (Multigrid.py:90 + :93 folded into the pre-smoothing pass):
+    // row (Y, X) of R reads r at (2Y * W + 2X) + c * W + d, c, d in {-1, 0, 1} (slots 0..8); nc, Wc as above
+    double *bc;
+    const unsigned char *rpid;
+    const double *rp_val;     // [rp_npat][9]
+    const int *rp_mask;       // [rp_npat]
+    int rp_npat;
 };
 
-template <int S, unsigned UM, bool RESID, bool ZERO, int RR, bool PROL = false>
+template <int S, unsigned UM, bool RESID, bool ZERO, int RR, bool PROL = false, bool REST = false>
 __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
 {
     static_assert(!PROL || (!RESID && !ZERO), "the correction is folded into post-smoothing passes only");
-    constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);
+    static_assert(!REST || (RESID && !PROL), "the restriction replaces the store of the residual");
+    // halo: one more with REST -- the residual has to be exact one line / column beyond the stored part
+    constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0) + (REST ? 1 : 0);
     static_assert(RR > 2 * H + 1 && kCols > 2 * H && RR % kWaves == 0, "tile smaller than its halo / lines per wave");
     // LDS holds the two iterate buffers only: right-hand side and pattern ids of a wave's own lines never change and
     // stay in its registers (32-line tiles: 39 KB instead of 60, i.e. four workgroups per CU instead of two).
@@ -75,6 +84,8 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
     __shared__ double s_rdiag[kMaxPat];
     __shared__ double s_pv[PROL ? kMaxPat * 4 : 1];
     __shared__ int s_pm[PROL ? kMaxPat : 1];
+    __shared__ double s_rv[REST ? kMaxPat * 9 : 1];
+    __shared__ int s_rm[REST ? kMaxPat : 1];
 
     const int t = threadIdx.x, lane = t & (LMG_WAVE - 1), wave = t >> 6;
     const int tx = (int)blockIdx.x % a.tiles_x, ty = (int)blockIdx.x / a.tiles_x;
@@ -89,7 +100,7 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
     double lx[RB], bk[RB];
     int pk[RB];                                                   // pattern id | 0x100 where the element is a row of the matrix
     double le[PROL ? RB : 1][4];                                  // PROL: the 2 x 2 coarse window of every element
-    int lq[PROL ? RB : 1];                                        //       and its pattern id in P
+    int lq[(PROL || REST) ? RB : 1];                              //       and its pattern id in P / REST: the id of R's row
 #pragma unroll
     for (int k = 0; k < RB; ++k) {
         const int y = y0 + rb0 + k;
@@ -110,6 +121,13 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
                 const int64_t jc = base + (q & 1) + (q >> 1) * (int64_t)a.Wc;
                 le[k][q] = a.ec[jc < a.nc ? jc : a.nc - 1];       // (slots a pattern does not have may point anywhere)
             }
+        }
+        if (REST) {
+            // elements on (even line, even column) of the grid carry a row of R
+            const int c = c0 + lane;
+            const bool crow = ok && !(y & 1) && !(c & 1) && c >= 0 && c < W;
+            const int64_t jc = (int64_t)(y >> 1) * a.Wc + (c >> 1);
+            lq[k] = crow ? ((int)a.rpid[jc < a.nc ? jc : 0] | 0x100) : 0;
         }
     }
     for (int i = t; i < a.npat * 9; i += kBlock) s_val[i] = a.st_val[i];
@@ -140,6 +158,10 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
             }
             lx[k] = (pk[k] >> 8) ? lx[k] + acc : 0.0;
         }
+    }
+    if (REST) {
+        for (int i = t; i < a.rp_npat * 9; i += kBlock) s_rv[i] = a.rp_val[i];
+        for (int i = t; i < a.rp_npat; i += kBlock) s_rm[i] = a.rp_mask[i];
     }
     const int hot = a.hot >= 0 ? (a.hot | 0x100) : -1;
     bool mine = true;
@@ -245,7 +267,32 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
     // ---- outputs: the inner part of the tile, inside the line, rows of the matrix --------------------------------
     const double *fin = s_x[S & 1];
     const bool col_ok = lane >= H && lane < kCols - H && c0 + lane >= 0 && c0 + lane < W;
-    if (RESID) {
+    if (REST) {
+        // the residual goes to the other LDS buffer (all lines but the first and the last: exact where it is read),
+        // then every element that carries a row of R sums its nine entries in column order -- the sums of
+        // lmg_rpat_sweep_grid(SPMV, alpha = 1, beta = 0)
+        double *rl = s_x[(S + 1) & 1];
+        block(fin, 1, RR - 1, [&](int k, bool keep, bool, double xc, double acc) {
+            const int r = rb0 + k;
+            if (keep) rl[r * kLS + 1 + lane] = bk[k] - acc;
+            if (r >= H && r < RR - H && col_ok && (pk[k] >> 8)) a.out[(int64_t)(y0 + r) * W + c0 + lane] = xc;
+        });
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            const int r = rb0 + k;
+            const int q = lq[k] & 0xff, m = s_rm[q];
+            double acc = 0.0;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) {
+                const int rr = min(max(r + e / 3 - 1, 0), RR - 1);
+                const double tv = acc + s_rv[q * 9 + e] * rl[rr * kLS + 1 + lane + e % 3 - 1];
+                acc = ((m >> e) & 1) ? tv : acc;
+            }
+            if ((lq[k] >> 8) && r >= H && r < RR - H && col_ok)
+                a.bc[(int64_t)((y0 + r) >> 1) * a.Wc + ((c0 + lane) >> 1)] = acc;
+        }
+    } else if (RESID) {
         block(fin, H, RR - H, [&](int k, bool keep, bool, double xc, double acc) {
             const int64_t i = (int64_t)(y0 + rb0 + k) * W + c0 + lane;
             if (keep && col_ok && (pk[k] >> 8)) {
@@ -267,15 +314,15 @@ int g_tile_rows = 0;        // 0 = chosen per launch (tuning: 16, 24, 32)
 int g_tile_rows_big = 0;    // the same for grids of at least g_tile_big_lines lines (tuning one level of a cycle)
 int g_tile_big_lines = 0x7fffffff;
 
-template <int S, unsigned UM, bool RESID, bool ZERO, int RR, bool PROL = false>
+template <int S, unsigned UM, bool RESID, bool ZERO, int RR, bool PROL = false, bool REST = false>
 int launch5(TArgs a, hipStream_t st)
 {
-    constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);
+    constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0) + (REST ? 1 : 0);
     a.tiles_x = (a.W + (kCols - 2 * H) - 1) / (kCols - 2 * H);
     a.tiles_y = (a.lines + (RR - 2 * H) - 1) / (RR - 2 * H);
     const int64_t grid = (int64_t)a.tiles_x * a.tiles_y;
     if (grid > 0x7fffffff) return LMG_ERR_CAPACITY;
-    hipLaunchKernelGGL((stencil_tile_kernel<S, UM, RESID, ZERO, RR, PROL>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((stencil_tile_kernel<S, UM, RESID, ZERO, RR, PROL, REST>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }
@@ -300,6 +347,16 @@ int launch_prol(TArgs a, int sweeps, hipStream_t st)
     case 1: return launch5<1, UM, false, false, 16, true>(a, st);
     case 2: return launch5<2, UM, false, false, 16, true>(a, st);
     default: return launch5<3, UM, false, false, 16, true>(a, st);
+    }
+}
+
+template <unsigned UM>
+int launch_rest(TArgs a, int sweeps, bool zero, hipStream_t st)
+{
+    switch (sweeps) {
+    case 1: return zero ? launch5<1, UM, true, true, 16, false, true>(a, st) : launch5<1, UM, true, false, 16, false, true>(a, st);
+    case 2: return zero ? launch5<2, UM, true, true, 16, false, true>(a, st) : launch5<2, UM, true, false, 16, false, true>(a, st);
+    default: return zero ? launch5<3, UM, true, true, 16, false, true>(a, st) : launch5<3, UM, true, false, 16, false, true>(a, st);
     }
 }
 
@@ -383,6 +440,11 @@ static int tile_args(TArgs &a, int64_t n, int32_t line_stride, const uint8_t *pi
     a.pp_val = nullptr;
     a.pp_mask = nullptr;
     a.pp_npat = 0;
+    a.bc = nullptr;
+    a.rpid = nullptr;
+    a.rp_val = nullptr;
+    a.rp_mask = nullptr;
+    a.rp_npat = 0;
     return 1;                                  // filled: launch
 }
 
@@ -429,6 +491,40 @@ int lmg_stencil_smooth_tiled_prolong(int64_t n, int32_t line_stride, const uint8
     switch (union_mask) {
     case kMask5: return launch_prol<kMask5>(a, sweeps, st);
     case kMask9: return launch_prol<kMask9>(a, sweeps, st);
+    default: return LMG_ERR_CAPACITY;
+    }
+}
+
+int lmg_stencil_smooth_tiled_restrict(int64_t n, int32_t line_stride, const uint8_t *pid, int32_t npat, const double *st_val,
+                                      const int32_t *st_mask, uint32_t union_mask, int32_t hot_pattern,
+                                      const double *h_hot_val, int sweeps, const double *x_in, const double *b, double omega,
+                                      double *x_out, int64_t n_coarse, int32_t coarse_stride, double *b_coarse,
+                                      const uint8_t *r_pid, int32_t r_npat, const double *r_val, const int32_t *r_mask,
+                                      void *stream)
+{
+    if (!b_coarse || !r_pid || !r_val || !r_mask || r_npat < 1 || r_npat > kMaxPat) return LMG_ERR_ARG;
+    if (n_coarse < 1 || n_coarse >= (1ll << 31) || coarse_stride < 1 || coarse_stride > n_coarse) return LMG_ERR_ARG;
+    if ((const double *)b_coarse == x_in || b_coarse == x_out || (const double *)b_coarse == b) return LMG_ERR_ARG;
+    // every fine node (even line, even column) must have its coarse row
+    const int64_t lines = n > 0 ? (n + line_stride - 1) / line_stride : 0;
+    if ((int64_t)coarse_stride < ((int64_t)line_stride + 1) / 2 || n_coarse < ((lines + 1) / 2 - 1) * coarse_stride + (line_stride + 1) / 2)
+        return LMG_ERR_ARG;
+    TArgs a;
+    const int rc = tile_args(a, n, line_stride, pid, npat, st_val, st_mask, union_mask, hot_pattern, h_hot_val, sweeps, x_in, b,
+                             omega, x_out, nullptr);
+    if (rc != 1) return rc;
+    a.bc = b_coarse;
+    a.nc = (int)n_coarse;
+    a.Wc = coarse_stride;
+    a.rpid = r_pid;
+    a.rp_val = r_val;
+    a.rp_mask = r_mask;
+    a.rp_npat = r_npat;
+    hipStream_t st = lmg_stream(stream);
+    const bool zero = x_in == nullptr;
+    switch (union_mask) {
+    case kMask5: return launch_rest<kMask5>(a, sweeps, zero, st);
+    case kMask9: return launch_rest<kMask9>(a, sweeps, zero, st);
     default: return LMG_ERR_CAPACITY;
     }
 }

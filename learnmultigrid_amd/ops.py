@@ -758,6 +758,12 @@ def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None, prolong=None, r
         _vec_ok(bc)
         if T is None or r_out is not None or prolong is not None or T.n != S.n or T.W != S.W or bc.numel() != T.nc:
             raise LmgError("stencil_smooth: this restriction cannot be fused into the pass")
+        if _fused_kind(A) == "tile":
+            check(_lib.lib().lmg_stencil_smooth_tiled_restrict(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask,
+                                                               S.hot, hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out),
+                                                               T.nc, T.Wc, _p(bc), _p(T.pid), T.npat, _p(T.r_val), _p(T.r_mask),
+                                                               _s()), "lmg_stencil_smooth_tiled_restrict")
+            return
         hr = None if T._hot_val is None else ctypes.addressof(T._hot_val)
         check(_lib.lib().lmg_stencil_smooth_restrict(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask, S.hot,
                                                      hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out), T.nc, T.Wc,
@@ -821,6 +827,10 @@ def stencil_smooth_prolong_available(A, P):
 
 
 _FUSED_RESTRICT_ENABLED = True
+# The tiled pass folds the restriction in only on levels of <= 2 M rows: it costs one more halo line / column per tile
+# (30 % more arithmetic at 16-line tiles), which a level of 4 M rows no longer gets back from the saved launch
+# (cfg#4 cycle 0.715 vs 0.720 ms without, 0.731 with it on every level; cfg#2 0.151 vs 0.157 ms).
+TILED_RESTRICT_MAX_ROWS = 2_000_000
 
 
 def set_fused_restrict_enabled(flag):
@@ -835,8 +845,12 @@ def stencil_smooth_restrict_available(A, R):
     restriction from A's grid with a coarse row under every (even line, even column) node."""
     T = getattr(R, "restrict", None)
     S = getattr(A, "stencil", None)
-    if not (_FUSED_RESTRICT_ENABLED and T is not None and _fused_kind(A) == "reg" and T.n == S.n and T.W == S.W
-            and S.n >= FUSED_TRANSFER_MIN_ROWS and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask)):
+    kind = _fused_kind(A)
+    if not (_FUSED_RESTRICT_ENABLED and T is not None and kind is not None and T.n == S.n and T.W == S.W):
+        return False
+    if kind == "reg" and not (S.n >= FUSED_TRANSFER_MIN_ROWS and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask)):
+        return False
+    if kind == "tile" and S.n > TILED_RESTRICT_MAX_ROWS:
         return False
     lines = (S.n + S.W - 1) // S.W
     return T.nc >= ((lines + 1) // 2 - 1) * T.Wc + (S.W + 1) // 2

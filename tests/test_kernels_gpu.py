@@ -1154,7 +1154,7 @@ def test_fused_post_smoothing_with_the_correction_folded_in(m, kind, seg_lines):
 
 
 @pytest.mark.parametrize("m,kind", [(64, "5pt"), (150, "5pt"), (64, "9pt"), (129, "9pt")])
-@pytest.mark.parametrize("seg_lines", [0, 5, 6, 1000])
+@pytest.mark.parametrize("seg_lines", [0, 5, 6, 1000, "tile"])
 def test_fused_pre_smoothing_with_the_restriction_folded_in(m, kind, seg_lines):
     """lmg_stencil_smooth_restrict: x_out = J^S(x), b_c = R (b - A x_out) in one pass without storing the residual,
     against the oracle's S Jacobi sweeps, residual and restriction (K.spmv with R = P^T), bitwise; zero and
@@ -1177,6 +1177,12 @@ def test_fused_pre_smoothing_with_the_restriction_folded_in(m, kind, seg_lines):
     rng = np.random.default_rng(6)
     x0, b = rng.standard_normal(n), rng.standard_normal(n)
     try:
+        if seg_lines == "tile":                            # the LDS-tiled pass: what these sizes run in the product
+            seg_lines = 0
+            assert ops._fused_kind(dA) == "tile" and ops.stencil_smooth_restrict_available(dA, dR)
+        else:
+            ops.set_tiled_enabled(False)
+            assert ops._fused_kind(dA) is None
         ops.tune_set("fused_seg_lines", seg_lines)
         for zero in (False, True):
             want = np.zeros(n) if zero else x0.copy()
@@ -1199,6 +1205,7 @@ def test_fused_pre_smoothing_with_the_restriction_folded_in(m, kind, seg_lines):
         assert np.array_equal(bc.cpu().numpy(), wbc)
     finally:
         ops.tune_set("fused_seg_lines", 0)
+        ops.set_tiled_enabled(True)
 
 
 def test_prolong_twin_only_for_two_by_two_window_transfers():

@@ -401,7 +401,7 @@ def test_full_size_properties_4097():
     # ... and the post-smoothing pass with the coarse-grid correction folded in (what the cycle above ran on the
     # two finest levels): prolongation + 3 sweeps of the oracle, bitwise
     lev0, lev1 = mg._hier.levels[0], mg._hier.levels[1]
-    assert ops.stencil_smooth_prolong_available(lev0.A, lev0.P) and not ops.stencil_smooth_prolong_available(lev1.A, lev1.P)
+    assert all(ops.stencil_smooth_prolong_available(lev.A, lev.P) for lev in mg._hier.levels[:-1])
     Pm = K.as_csr(hier[0])
     e = rng.standard_normal(Pm.shape[1])
     want = K.spmv(Pm, e, x0.copy(), 1.0, 1.0)
@@ -410,7 +410,8 @@ def test_full_size_properties_4097():
     ops.stencil_smooth(dA, dx, db, 0.8, 3, out, None, prolong=(lev0.P, torch.from_numpy(e).to("cuda:0")))
     assert np.array_equal(out.cpu().numpy(), want)
     # ... and the pre-smoothing pass with the restriction folded in (no residual vector is written)
-    assert ops.stencil_smooth_restrict_available(lev0.A, lev0.R) and not ops.stencil_smooth_restrict_available(lev1.A, lev1.R)
+    # (the restriction: register-blocked fine level and the tiled levels of <= 2 M rows)
+    assert [ops.stencil_smooth_restrict_available(lev.A, lev.R) for lev in mg._hier.levels[:-1]] == [True, False, True, True, True]
     want = x0
     for _ in range(3):
         want = K.jacobi(Ac, want, b, 0.8)

@@ -568,6 +568,8 @@ int g_fused_seg_lines = 0;      // 0 = chosen per launch
 int g_fused_seg_min_lines = 0;  // fused_seg_lines applies to grids of this many lines (tuning one level of a cycle)
 int g_fused_seg_max_lines = 0x7fffffff;
 int g_fused_pf = 0;             // 0 = default
+int g_fused_seg_lines_prol = 0; // segment length of the passes with the correction / the restriction folded in (0 = like the others)
+int g_fused_seg_lines_rest = 0;
 int g_fused_want_waves = 5120;  // waves a launch aims at when it cuts the lines into segments ...
 int g_fused_floor_halos = 4;    // ... which are never shorter than this many halos (the redundant lines of a segment: 2 H)
 
@@ -582,8 +584,13 @@ int launch4(MArgs a, hipStream_t st)
     // 28-line segments (5 145 waves), 0.90 with 24 or 47, 0.91 - 0.95 with 32 - 42; at 2049^2 the floor (12 lines) is
     // best, 0.91 vs 0.93 with 10 or 14 - 16 lines.
     int seg_lines = (a.lines >= g_fused_seg_min_lines && a.lines <= g_fused_seg_max_lines) ? g_fused_seg_lines : 0;
+    if (PROL && g_fused_seg_lines_prol > 0) seg_lines = g_fused_seg_lines_prol;
+    if (REST && g_fused_seg_lines_rest > 0) seg_lines = g_fused_seg_lines_rest;
     if (seg_lines <= 0) {
-        const int want_segs = (g_fused_want_waves + a.strips - 1) / a.strips;
+        // (the pass with the restriction folded in has the longest segments' halo, 2 x 5 lines: one round of waves --
+        // 3 per SIMD -- with 48-line segments measured best in the cycle, 0.701 vs 0.711 ms with 28 lines)
+        const int want = REST ? (g_fused_want_waves * 3) / 5 : g_fused_want_waves;
+        const int want_segs = (want + a.strips - 1) / a.strips;
         seg_lines = (a.lines + want_segs - 1) / want_segs;
         const int floor_lines = H > 0 ? g_fused_floor_halos * H : 4;
         if (seg_lines < floor_lines) seg_lines = floor_lines;
@@ -656,6 +663,11 @@ int lmg_fused_tune_set(const char *key, int v)
         g_fused_seg_min_lines = v;
         return LMG_OK;
     }
+    if (strcmp(key, "fused_seg_lines_prol") == 0 || strcmp(key, "fused_seg_lines_rest") == 0) {
+        if (v < 0) return LMG_ERR_ARG;
+        (key[16] == 'p' ? g_fused_seg_lines_prol : g_fused_seg_lines_rest) = v;
+        return LMG_OK;
+    }
     if (strcmp(key, "fused_seg_max_lines") == 0) {
         if (v < 0) return LMG_ERR_ARG;
         g_fused_seg_max_lines = v;
@@ -679,6 +691,8 @@ int lmg_fused_tune_get(const char *key)
     if (strcmp(key, "fused_pf") == 0) return g_fused_pf;
     if (strcmp(key, "fused_seg_min_lines") == 0) return g_fused_seg_min_lines;
     if (strcmp(key, "fused_seg_max_lines") == 0) return g_fused_seg_max_lines;
+    if (strcmp(key, "fused_seg_lines_prol") == 0) return g_fused_seg_lines_prol;
+    if (strcmp(key, "fused_seg_lines_rest") == 0) return g_fused_seg_lines_rest;
     if (strcmp(key, "fused_want_waves") == 0) return g_fused_want_waves;
     if (strcmp(key, "fused_floor_halos") == 0) return g_fused_floor_halos;
     return LMG_ERR_ARG;

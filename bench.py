@@ -42,14 +42,14 @@ PMC_TRAFFIC = {
     (4096, "pcsr"): (672639665, "profiles/r01_packed_sweep_pmc_fetch_write.txt"),
     (4096, "rpat"): (451701453, "profiles/r01_rpat_sweep_pmc_fetch_write.txt"),
     (4096, "stencil"): (420151166, "profiles/r02_stencil_sweep_pmc_fetch_write.txt"),
-    # the fused passes re-read halo lines / columns of neighbouring strips (28-line segments): 3 sweeps 2 x 202 071 KB +
-    # 133 019 KB; + residual 2 x 206 830 KB + 266 434 KB; + restricted residual (r not written) 2 x 235 383 KB +
-    # 167 046 KB; 3 sweeps with the correction folded in 2 x 247 234 KB + 132 993 KB
+    # the fused passes re-read halo lines / columns of neighbouring strips (28-line segments; 48 with the restriction):
+    # 3 sweeps 2 x 202 042 KB + 133 088 KB; + residual 2 x 206 810 KB + 266 517 KB; + restricted residual (r not written)
+    # 2 x 200 979 KB + 166 875 KB; 3 sweeps with the correction folded in 2 x 246 720 KB + 133 016 KB
     # (compulsory: 419.6 / 553.9 / 457.4 / 470.0 MB)
-    (4096, "fused"): (550052414, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
-    (4096, "fused_resid"): (696414816, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
-    (4096, "fused_restrict"): (653118214, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
-    (4096, "fused_prolong"): (642520154, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
+    (4096, "fused"): (550063968, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
+    (4096, "fused_resid"): (696460718, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
+    (4096, "fused_restrict"): (582484229, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
+    (4096, "fused_prolong"): (641489453, "profiles/r02_fused_pass_pmc_fetch_write.txt"),
 }
 
 

@@ -408,6 +408,13 @@ int lmg_dense_gemv_blockdiag(int64_t nblocks, int64_t bs, const double *d_M, con
 int lmg_dense_gemv_windows(int64_t nblocks, int64_t rows, int64_t cols, const double *d_M, const double *d_x,
                            int64_t x_stride, const double *d_z, int64_t z_stride, double alpha, double *d_y,
                            int64_t y_stride, void *stream);
+
+/* The same with a table of window starts: the x window of block k is d_x[d_x_offsets[k] .. + cols) (any 8-byte
+ * aligned start; the caller keeps every window inside the allocation).  Back-substitution of the banded coarse
+ * solver: x_I = y_I - (A_II^-1 A_IS) x_S in one launch (coarse.py BandedBlockSolver.apply). */
+int lmg_dense_gemv_windows_off(int64_t nblocks, int64_t rows, int64_t cols, const double *d_M, const double *d_x,
+                               const int32_t *d_x_offsets, const double *d_z, int64_t z_stride, double alpha,
+                               double *d_y, int64_t y_stride, void *stream);
 int lmg_block_copy(int64_t nblocks, int64_t bs, const double *d_src, int64_t src_stride, double *d_dst,
                    int64_t dst_stride, void *stream);
 

@@ -46,6 +46,9 @@ def csr_to_dense(A):
     return dense
 
 
+BACKSUB_ONE_LAUNCH = True     # banded solver: x_I = y_I - (A_II^-1 A_IS) x_S instead of A_II^-1 (b_I - A_IS x_S)
+
+
 def _inv_schur(A, leaf=_INV_LEAF):
     """Recursive 2x2 Schur-complement inversion of A (..., n, n): only small (batched) leaf
     inversions and plain rocBLAS GEMMs (torch.matmul).  No pivoting across blocks; the callers
@@ -265,7 +268,12 @@ class BandedBlockSolver:
         self.A_IS = DeviceCSR(t(IS_pat.indptr, torch.int32), t(IS_pat.indices, torch.int32), z64(IS_pat.nnz), (nI, nS))
         self.A_SI = DeviceCSR(t(SI_pat.indptr, torch.int32), t(SI_pat.indices, torch.int32), z64(SI_pat.nnz), (nS, nI))
         self.perm = t(perm, torch.int32)
-        self.bp, self.xp, self.y, self.t = z64(n), z64(n), z64(nI), z64(nI)
+        # back-substitution in one launch: x_I = y_I - W x_S with W = A_II^-1 A_IS per strip (s x cw, cw padded to even;
+        # window starts ws[i] in x_S; x_S is followed by zeros so that the last window stays inside)
+        self.cwp = cw + (cw & 1)
+        self._ws = t32(ws)
+        self.bp, self.xp, self.y, self.t = z64(n), z64(n + self.cwp + 2), z64(nI), z64(nI)
+        self.W = None
         self.blocks = torch.zeros((k, s, s), dtype=F64, device=dev)
         self.Sinv = None
         self._nnz = int(cols.size)
@@ -293,7 +301,14 @@ class BandedBlockSolver:
         self.blocks = dense_inverse(dense)            # all strips as one batch
         ais = self._place(v, self._src_IS, self._dst_IS, k * s * cw)
         asi = self._place(v, self._src_SI, self._dst_SI, k * cw * s)
-        upd = torch.bmm(asi.view(k, cw, s), torch.bmm(self.blocks, ais.view(k, s, cw)))      # k x cw x cw
+        w_ = torch.bmm(self.blocks, ais.view(k, s, cw))                                      # k x s x cw: A_II^-1 A_IS
+        upd = torch.bmm(asi.view(k, cw, s), w_)                                              # k x cw x cw
+        if BACKSUB_ONE_LAUNCH and hasattr(self.ops, "dense_gemv_windows_off"):
+            self.W = torch.zeros((k, s, self.cwp), dtype=F64, device=dev)
+            self.W[:, :, :cw] = w_
+        else:
+            self.W = None
+        del w_
         Sc = self._place(v, self._src_SS, self._dst_SS, nS * nS)
         upd = upd.reshape(-1)
         for sel, dst in self._upd:                       # S[dst] -= upd[sel], every destination once per pass
@@ -315,16 +330,21 @@ class BandedBlockSolver:
         nI = self.nI
         o.gather(self.perm, b, self.bp)                           # permuted rhs [b_I | b_S]
         bI, bS = self.bp[:nI], self.bp[nI:]
-        xI, xS = self.xp[:nI], self.xp[nI:]
+        xI, xS = self.xp[:nI], self.xp[nI:nI + self.nS]
         o.dense_gemv_blockdiag(self.blocks, bI, self.y)           # y_I = A_II^-1 b_I
         o.csr_spmv(self.A_SI, self.y, bS, -1.0, 1.0)              # g_S = b_S - A_SI y_I   (in place)
         o.dense_gemv(self.Sinv, bS, xS)                           # x_S = S^-1 g_S
-        o.csr_residual_norm2(self.A_IS, xS, bI, self.t, None, None)      # t_I = b_I - A_IS x_S (one launch)
-        o.dense_gemv_blockdiag(self.blocks, self.t, xI)           # x_I = A_II^-1 t_I
-        o.scatter(self.perm, self.xp, x)
+        if self.W is not None and BACKSUB_ONE_LAUNCH:
+            # x_I = y_I - (A_II^-1 A_IS) x_S: one launch over 8 k s cw bytes instead of an SpMV and 8 k s^2
+            o.dense_gemv_windows_off(self.W, self.xp[nI:], self._ws, xI, self.s, z=self.y, z_stride=self.s, alpha=-1.0)
+        else:
+            o.csr_residual_norm2(self.A_IS, xS, bI, self.t, None, None)      # t_I = b_I - A_IS x_S (one launch)
+            o.dense_gemv_blockdiag(self.blocks, self.t, xI)           # x_I = A_II^-1 t_I
+        o.scatter(self.perm, self.xp[:self.n], x)
 
     def bytes_per_apply(self):
-        return 8 * (2 * self.k * self.s * self.s + self.nS * self.nS)
+        back = self.k * self.s * self.cwp if self.W is not None else self.k * self.s * self.s
+        return 8 * (self.k * self.s * self.s + back + self.nS * self.nS)
 
 
 class BlockCyclicReduction:

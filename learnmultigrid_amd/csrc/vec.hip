@@ -196,6 +196,32 @@ __global__ void __launch_bounds__(kBlock) dense_gemv_windows_kernel(int64_t nb, 
     }
 }
 
+// The same with a table of window starts instead of a stride: x window of block k = x0[xoff[k] .. xoff[k] + cols)
+// (the banded coarse solver's back-substitution x_I = y_I - (A_II^-1 A_IS) x_S: strip k couples to the separators on
+// either side of it, which start at irregular offsets; 8-byte aligned windows are enough for the 16-byte loads).
+__global__ void __launch_bounds__(kBlock) dense_gemv_windows_off_kernel(int64_t nb, int64_t rows, int64_t cols,
+                                                                        const double *M, const double *x0, const int *xoff,
+                                                                        const double *z0, int64_t zs, double alpha,
+                                                                        double *y0, int64_t ys)
+{
+    const int lane = threadIdx.x & (LMG_WAVE - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LMG_WAVE;
+    const int64_t nwaves = (int64_t)gridDim.x * kBlock / LMG_WAVE;
+    for (int64_t row = wave; row < nb * rows; row += nwaves) {
+        const int64_t k = row / rows, r = row - k * rows;
+        const double2 *M2 = reinterpret_cast<const double2 *>(M + row * cols);
+        const double *x = x0 + xoff[k];
+        double s = 0.0;
+        for (int64_t j = lane; j < cols / 2; j += LMG_WAVE) {
+            const double2 mv = M2[j];
+            s += mv.x * x[2 * j];
+            s += mv.y * x[2 * j + 1];
+        }
+        s = lmg_wave_sum(s);
+        if (lane == 0) y0[k * ys + r] = (z0 ? z0[k * zs + r] : 0.0) + alpha * s;
+    }
+}
+
 // dense[i][colidx[e]] += vals[e] for the entries e of row i (dense zero-initialised by the caller)
 __global__ void __launch_bounds__(kBlock) csr_to_dense_kernel(int64_t n, int64_t m, const int *rowptr, const int *colidx,
                                                               const double *vals, double *dense)
@@ -539,6 +565,20 @@ int lmg_dense_gemv_windows(int64_t nblocks, int64_t rows, int64_t cols, const do
     if (!lmg_aligned16(M) || !lmg_aligned16(x) || (cols % 2) || (x_stride % 2)) return LMG_ERR_ALIGN;
     hipLaunchKernelGGL(dense_gemv_windows_kernel, dim3(grid_for(nblocks * rows, kBlock / LMG_WAVE)), dim3(kBlock), 0,
                        lmg_stream(stream), nblocks, rows, cols, M, x, x_stride, z, z_stride, alpha, y, y_stride);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_dense_gemv_windows_off(int64_t nblocks, int64_t rows, int64_t cols, const double *M, const double *x,
+                               const int32_t *x_offsets, const double *z, int64_t z_stride, double alpha, double *y,
+                               int64_t y_stride, void *stream)
+{
+    if (nblocks < 0 || rows < 0 || cols < 0 || y_stride < rows || (z && z_stride < 0)) return LMG_ERR_ARG;
+    if (nblocks * rows == 0) return LMG_OK;
+    if (!M || !x || !x_offsets || !y || x == y) return LMG_ERR_ARG;
+    if (!lmg_aligned16(M) || (cols % 2)) return LMG_ERR_ALIGN;
+    hipLaunchKernelGGL(dense_gemv_windows_off_kernel, dim3(grid_for(nblocks * rows, kBlock / LMG_WAVE)), dim3(kBlock), 0,
+                       lmg_stream(stream), nblocks, rows, cols, M, x, x_offsets, z, z_stride, alpha, y, y_stride);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }

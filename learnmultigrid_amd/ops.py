@@ -1188,6 +1188,14 @@ def dense_gemv_windows(M, x, x_stride, y, y_stride, z=None, z_stride=0, alpha=1.
                                             _p(y), int(y_stride), _s()), "lmg_dense_gemv_windows")
 
 
+def dense_gemv_windows_off(M, x, x_offsets, y, y_stride, z=None, z_stride=0, alpha=1.0):
+    """dense_gemv_windows with a table of window starts (int32 tensor, one per block) instead of a stride."""
+    _vec_ok(M, x, y, z)
+    nb, rows, cols = M.shape
+    check(_lib.lib().lmg_dense_gemv_windows_off(nb, rows, cols, _p(M), _p(x), _p(x_offsets), _p(z), int(z_stride), float(alpha),
+                                                _p(y), int(y_stride), _s()), "lmg_dense_gemv_windows_off")
+
+
 def csr_to_dense(A, dense):
     check(_lib.lib().lmg_csr_to_dense(A.shape[0], A.shape[1], _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(dense), _s()),
           "lmg_csr_to_dense")

@@ -119,6 +119,17 @@ def dense_gemv_windows(M, x, x_stride, y, y_stride, z=None, z_stride=0, alpha=1.
         yn[k * y_stride:k * y_stride + rows] = out[k]
 
 
+def dense_gemv_windows_off(M, x, x_offsets, y, y_stride, z=None, z_stride=0, alpha=1.0):
+    nb, rows, cols = M.shape
+    Mn, xn, yn, off = _np(M), _np(x), _np(y), _np(x_offsets)
+    zn = None if z is None else _np(z)
+    out = [(zn[k * z_stride:k * z_stride + rows] if zn is not None else 0.0)
+           + alpha * K.dense_gemv(np.ascontiguousarray(Mn[k]), np.ascontiguousarray(xn[off[k]:off[k] + cols]))
+           for k in range(nb)]
+    for k in range(nb):
+        yn[k * y_stride:k * y_stride + rows] = out[k]
+
+
 def block_copy(nblocks, bs, src, src_stride, dst, dst_stride):
     sn, dn = _np(src), _np(dst)
     for k in range(nblocks):

@@ -415,6 +415,18 @@ int lmg_dense_gemv_windows(int64_t nblocks, int64_t rows, int64_t cols, const do
 int lmg_dense_gemv_windows_off(int64_t nblocks, int64_t rows, int64_t cols, const double *d_M, const double *d_x,
                                const int32_t *d_x_offsets, const double *d_z, int64_t z_stride, double alpha,
                                double *d_y, int64_t y_stride, void *stream);
+
+/* First and last product of the banded coarse solver (coarse.py) with its permutation perm = [strip unknowns |
+ * separator unknowns] folded in, so that no gather / scatter launch surrounds the solve:
+ *   lmg_coarse_front: y = blockdiag(M) b[perm[0 .. nblocks*bs)],  tail_out[i] = b[perm[nblocks*bs + i]], i < ntail;
+ *   lmg_coarse_back : out[perm[k*rows + r]] (+)= z[k*z_stride + r] + alpha * M_k[r,:] . x[x_offsets[k] ..),
+ *                     out[perm[nblocks*rows + i]] (+)= x[i], i < ntail   (accumulate != 0: += , the refinement step).
+ * Same sums as lmg_dense_gemv_blockdiag / lmg_dense_gemv_windows_off followed by lmg_gather / lmg_scatter / lmg_axpby. */
+int lmg_coarse_front(int64_t nblocks, int64_t bs, const double *d_M, const double *d_b, const int32_t *d_perm, double *d_y,
+                     int64_t ntail, double *d_tail_out, void *stream);
+int lmg_coarse_back(int64_t nblocks, int64_t rows, int64_t cols, const double *d_M, const double *d_x,
+                    const int32_t *d_x_offsets, const double *d_z, int64_t z_stride, double alpha, const int32_t *d_perm,
+                    double *d_out, int accumulate, int64_t ntail, void *stream);
 int lmg_block_copy(int64_t nblocks, int64_t bs, const double *d_src, int64_t src_stride, double *d_dst,
                    int64_t dst_stride, void *stream);
 

@@ -46,6 +46,7 @@ def csr_to_dense(A):
     return dense
 
 
+FOLD_PERMUTATION = True       # banded solver: gather / scatter folded into the first / last product (A/B switch)
 BACKSUB_ONE_LAUNCH = True     # banded solver: x_I = y_I - (A_II^-1 A_IS) x_S instead of A_II^-1 (b_I - A_IS x_S)
 
 
@@ -273,6 +274,7 @@ class BandedBlockSolver:
         self.cwp = cw + (cw & 1)
         self._ws = t32(ws)
         self.bp, self.xp, self.y, self.t = z64(n), z64(n + self.cwp + 2), z64(nI), z64(nI)
+        self._acc = z64(n)
         self.W = None
         self.blocks = torch.zeros((k, s, s), dtype=F64, device=dev)
         self.Sinv = None
@@ -325,12 +327,27 @@ class BandedBlockSolver:
         self.A_IS.invalidate_packed()
         self.A_SI.invalidate_packed()
 
-    def apply(self, b, x):
+    supports_accumulate = True
+
+    def apply(self, b, x, accumulate=False):
+        """x = A^-1 b; accumulate: x += A^-1 b (the refinement step of Hierarchy.coarse_solve without a temporary)."""
         o = self.ops
         nI = self.nI
-        o.gather(self.perm, b, self.bp)                           # permuted rhs [b_I | b_S]
+        folded = self.W is not None and BACKSUB_ONE_LAUNCH and FOLD_PERMUTATION and hasattr(o, "coarse_front")
         bI, bS = self.bp[:nI], self.bp[nI:]
         xI, xS = self.xp[:nI], self.xp[nI:nI + self.nS]
+        if folded:
+            # the permutation [strips | separators] is folded into the first and the last product: 4 launches
+            o.coarse_front(self.blocks, b, self.perm, self.y, bS)     # y_I = A_II^-1 b_I, b_S gathered on the side
+            o.csr_spmv(self.A_SI, self.y, bS, -1.0, 1.0)              # g_S = b_S - A_SI y_I   (in place)
+            o.dense_gemv(self.Sinv, bS, xS)                           # x_S = S^-1 g_S
+            o.coarse_back(self.W, self.xp[nI:], self._ws, self.y, -1.0, self.perm, x, accumulate, self.nS)
+            return
+        if accumulate:
+            self.apply(b, self._acc)
+            o.axpby(1.0, self._acc, 1.0, x)
+            return
+        o.gather(self.perm, b, self.bp)                           # permuted rhs [b_I | b_S]
         o.dense_gemv_blockdiag(self.blocks, bI, self.y)           # y_I = A_II^-1 b_I
         o.csr_spmv(self.A_SI, self.y, bS, -1.0, 1.0)              # g_S = b_S - A_SI y_I   (in place)
         o.dense_gemv(self.Sinv, bS, xS)                           # x_S = S^-1 g_S

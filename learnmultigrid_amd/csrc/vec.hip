@@ -222,6 +222,65 @@ __global__ void __launch_bounds__(kBlock) dense_gemv_windows_off_kernel(int64_t 
     }
 }
 
+// First and last product of the banded coarse solver with the permutation [strips | separators] folded in (no
+// gather / scatter launches around the solve):
+//   front: y = blockdiag(M) * b[perm[0 .. nI)]   and   tail_out[i] = b[perm[nI + i]]            (i < ntail)
+//   back : out[perm[k*rows + r]] (+)= z[k*zs + r] + alpha * M_k[r,:] . x[xoff[k] ..)   and
+//          out[perm[nI + i]] (+)= x[i]                                                          (i < ntail)
+// Same lane sums and reductions as dense_gemv_kernel / dense_gemv_windows_off_kernel.
+__global__ void __launch_bounds__(kBlock) coarse_front_kernel(int64_t n, int64_t bs, const double *M, const double *b,
+                                                              const int *perm, double *y, int64_t ntail, double *tail_out)
+{
+    const int lane = threadIdx.x & (LMG_WAVE - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LMG_WAVE;
+    const int64_t nwaves = (int64_t)gridDim.x * kBlock / LMG_WAVE;
+    for (int64_t row = wave; row < n; row += nwaves) {
+        const double2 *M2 = reinterpret_cast<const double2 *>(M + row * bs);
+        const int *p = perm + (row / bs) * bs;
+        double s = 0.0;
+        for (int64_t j = lane; j < bs / 2; j += LMG_WAVE) {
+            const double2 mv = M2[j];
+            s += mv.x * b[p[2 * j]];
+            s += mv.y * b[p[2 * j + 1]];
+        }
+        s = lmg_wave_sum(s);
+        if (lane == 0) y[row] = s;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ntail; i += (int64_t)gridDim.x * kBlock)
+        tail_out[i] = b[perm[n + i]];
+}
+
+__global__ void __launch_bounds__(kBlock) coarse_back_kernel(int64_t nb, int64_t rows, int64_t cols, const double *M,
+                                                             const double *x0, const int *xoff, const double *z0, int64_t zs,
+                                                             double alpha, const int *perm, double *out, int accumulate,
+                                                             int64_t ntail)
+{
+    const int lane = threadIdx.x & (LMG_WAVE - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LMG_WAVE;
+    const int64_t nwaves = (int64_t)gridDim.x * kBlock / LMG_WAVE;
+    for (int64_t row = wave; row < nb * rows; row += nwaves) {
+        const int64_t k = row / rows, r = row - k * rows;
+        const double2 *M2 = reinterpret_cast<const double2 *>(M + row * cols);
+        const double *x = x0 + xoff[k];
+        double s = 0.0;
+        for (int64_t j = lane; j < cols / 2; j += LMG_WAVE) {
+            const double2 mv = M2[j];
+            s += mv.x * x[2 * j];
+            s += mv.y * x[2 * j + 1];
+        }
+        s = lmg_wave_sum(s);
+        if (lane == 0) {
+            const double v = z0[k * zs + r] + alpha * s;
+            const int d = perm[row];
+            out[d] = accumulate ? v + out[d] : v;
+        }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ntail; i += (int64_t)gridDim.x * kBlock) {
+        const int d = perm[nb * rows + i];
+        out[d] = accumulate ? x0[i] + out[d] : x0[i];
+    }
+}
+
 // dense[i][colidx[e]] += vals[e] for the entries e of row i (dense zero-initialised by the caller)
 __global__ void __launch_bounds__(kBlock) csr_to_dense_kernel(int64_t n, int64_t m, const int *rowptr, const int *colidx,
                                                               const double *vals, double *dense)
@@ -579,6 +638,34 @@ int lmg_dense_gemv_windows_off(int64_t nblocks, int64_t rows, int64_t cols, cons
     if (!lmg_aligned16(M) || (cols % 2)) return LMG_ERR_ALIGN;
     hipLaunchKernelGGL(dense_gemv_windows_off_kernel, dim3(grid_for(nblocks * rows, kBlock / LMG_WAVE)), dim3(kBlock), 0,
                        lmg_stream(stream), nblocks, rows, cols, M, x, x_offsets, z, z_stride, alpha, y, y_stride);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_coarse_front(int64_t nblocks, int64_t bs, const double *M, const double *b, const int32_t *perm, double *y,
+                     int64_t ntail, double *tail_out, void *stream)
+{
+    if (nblocks < 0 || bs < 0 || ntail < 0 || (nblocks * bs > 0 && (!M || !b || !perm || !y)) || (ntail > 0 && !tail_out) || b == y)
+        return LMG_ERR_ARG;
+    if (nblocks * bs == 0 && ntail == 0) return LMG_OK;
+    if (!lmg_aligned16(M) || (bs % 2)) return LMG_ERR_ALIGN;
+    hipLaunchKernelGGL(coarse_front_kernel, dim3(grid_for(nblocks * bs > 0 ? nblocks * bs : 1, kBlock / LMG_WAVE)), dim3(kBlock), 0,
+                       lmg_stream(stream), nblocks * bs, bs, M, b, perm, y, ntail, tail_out);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_coarse_back(int64_t nblocks, int64_t rows, int64_t cols, const double *M, const double *x, const int32_t *x_offsets,
+                    const double *z, int64_t z_stride, double alpha, const int32_t *perm, double *out, int accumulate,
+                    int64_t ntail, void *stream)
+{
+    if (nblocks < 0 || rows < 0 || cols < 0 || ntail < 0 || z_stride < 0) return LMG_ERR_ARG;
+    if (nblocks * rows == 0 && ntail == 0) return LMG_OK;
+    if (!M || !x || !x_offsets || !z || !perm || !out || x == out || z == out) return LMG_ERR_ARG;
+    if (!lmg_aligned16(M) || (cols % 2)) return LMG_ERR_ALIGN;
+    hipLaunchKernelGGL(coarse_back_kernel, dim3(grid_for(nblocks * rows > 0 ? nblocks * rows : 1, kBlock / LMG_WAVE)), dim3(kBlock), 0,
+                       lmg_stream(stream), nblocks, rows, cols, M, x, x_offsets, z, z_stride, alpha, perm, out, accumulate,
+                       ntail);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }

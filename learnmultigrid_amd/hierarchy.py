@@ -266,8 +266,11 @@ class Hierarchy:
         self.coarse.apply(lev.b, lev.x)
         for _ in range(self.coarse_refine):
             self.ops.csr_residual_norm2(lev.A, lev.x, lev.b, lev.r, None, None)
-            self.coarse.apply(lev.r, lev.tmp)
-            self.ops.axpby(1.0, lev.tmp, 1.0, lev.x)
+            if getattr(self.coarse, "supports_accumulate", False):
+                self.coarse.apply(lev.r, lev.x, accumulate=True)      # x += A^-1 r in the solver's last launch
+            else:
+                self.coarse.apply(lev.r, lev.tmp)
+                self.ops.axpby(1.0, lev.tmp, 1.0, lev.x)
 
     def cycle(self, smoother, steps, omega=1.0, gs_mode="lexicographic", l=0, depth=None,
               after_presmooth=None, x_is_zero=False):

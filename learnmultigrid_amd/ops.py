@@ -1196,6 +1196,21 @@ def dense_gemv_windows_off(M, x, x_offsets, y, y_stride, z=None, z_stride=0, alp
                                                 _p(y), int(y_stride), _s()), "lmg_dense_gemv_windows_off")
 
 
+def coarse_front(M, b, perm, y, tail_out):
+    """y = blockdiag(M) b[perm[:nI]], tail_out = b[perm[nI:]] in one launch (M: (k, s, s), nI = k * s)."""
+    _vec_ok(M, b, y, tail_out)
+    check(_lib.lib().lmg_coarse_front(M.shape[0], M.shape[1], _p(M), _p(b), _p(perm), _p(y), tail_out.numel(), _p(tail_out), _s()),
+          "lmg_coarse_front")
+
+
+def coarse_back(W, x_tail, x_offsets, z, alpha, perm, out, accumulate, ntail):
+    """out[perm[:nI]] (+)= z + alpha * W_k . x_tail[x_offsets[k]:...], out[perm[nI:nI + ntail]] (+)= x_tail[:ntail]."""
+    _vec_ok(W, x_tail, z, out)
+    nb, rows, cols = W.shape
+    check(_lib.lib().lmg_coarse_back(nb, rows, cols, _p(W), _p(x_tail), _p(x_offsets), _p(z), rows, float(alpha), _p(perm),
+                                     _p(out), 1 if accumulate else 0, int(ntail), _s()), "lmg_coarse_back")
+
+
 def csr_to_dense(A, dense):
     check(_lib.lib().lmg_csr_to_dense(A.shape[0], A.shape[1], _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(dense), _s()),
           "lmg_csr_to_dense")

@@ -16,8 +16,7 @@
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kWaves = kBlock / LMG_WAVE;
+constexpr int kRB = 4;                        // consecutive lines of a tile a wave owns: a tile of RR lines is RR / 4 waves
 constexpr int kMaxPat = 64;
 constexpr int kCols = 64;                     // columns of a tile = lanes of a wave
 constexpr int kLS = kCols + 2;                // LDS line stride: one guard column on either side
@@ -69,13 +68,14 @@ struct TArgs {
 };
 
 template <int S, unsigned UM, bool RESID, bool ZERO, int RR, bool PROL = false, bool REST = false>
-__global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
+__global__ void __launch_bounds__(RR / kRB * LMG_WAVE) stencil_tile_kernel(TArgs a)
 {
     static_assert(!PROL || (!RESID && !ZERO), "the correction is folded into post-smoothing passes only");
     static_assert(!REST || (RESID && !PROL), "the restriction replaces the store of the residual");
     // halo: one more with REST -- the residual has to be exact one line / column beyond the stored part
     constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0) + (REST ? 1 : 0);
-    static_assert(RR > 2 * H + 1 && kCols > 2 * H && RR % kWaves == 0, "tile smaller than its halo / lines per wave");
+    constexpr int kWaves = RR / kRB, kBlock = kWaves * LMG_WAVE;
+    static_assert(RR > 2 * H + 1 && kCols > 2 * H && RR % kRB == 0, "tile smaller than its halo / lines per wave");
     // LDS holds the two iterate buffers only: right-hand side and pattern ids of a wave's own lines never change and
     // stay in its registers (32-line tiles: 39 KB instead of 60, i.e. four workgroups per CU instead of two).
     __shared__ double s_x[2][RR * kLS];
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
     const int c0 = tx * (kCols - 2 * H) - H, y0 = ty * (RR - 2 * H) - H;
     const int n = a.n;
     const int64_t W = a.W;
-    constexpr int RB = RR / kWaves;                              // consecutive lines of the tile a wave owns
+    constexpr int RB = kRB;                                      // consecutive lines of the tile a wave owns
     constexpr bool DIAG = (UM & 0x145u) != 0;
     const int rb0 = wave * RB;
 
@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(kBlock) stencil_tile_kernel(TArgs a)
     }
 }
 
-int g_tile_rows = 0;        // 0 = chosen per launch (tuning: 16, 24, 32)
+int g_tile_rows = 0;        // 0 = chosen per launch (tuning: 16, 32)
 int g_tile_rows_big = 0;    // the same for grids of at least g_tile_big_lines lines (tuning one level of a cycle)
 int g_tile_big_lines = 0x7fffffff;
 
@@ -322,31 +322,31 @@ int launch5(TArgs a, hipStream_t st)
     a.tiles_y = (a.lines + (RR - 2 * H) - 1) / (RR - 2 * H);
     const int64_t grid = (int64_t)a.tiles_x * a.tiles_y;
     if (grid > 0x7fffffff) return LMG_ERR_CAPACITY;
-    hipLaunchKernelGGL((stencil_tile_kernel<S, UM, RESID, ZERO, RR, PROL, REST>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((stencil_tile_kernel<S, UM, RESID, ZERO, RR, PROL, REST>), dim3((unsigned)grid), dim3(RR / kRB * LMG_WAVE), 0, st, a);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }
 
-template <int S, unsigned UM, bool RESID, bool ZERO>
+static int tile_rows_for(const TArgs &a)
+{
+    const int rr = a.lines >= g_tile_big_lines ? g_tile_rows_big : g_tile_rows;
+    return rr == 0 ? 32 : rr;     // measured in the cycle (cfg#4): 0.677 ms with 32-line tiles (8 waves), 0.681 with 16 (4 waves)
+}
+
+template <int S, unsigned UM, bool RESID, bool ZERO, bool PROL = false, bool REST = false>
 int launch4(TArgs a, hipStream_t st)
 {
-    int rr = a.lines >= g_tile_big_lines ? g_tile_rows_big : g_tile_rows;
-    if (rr == 0) rr = 16;         // measured in the cycle (cfg#4): 0.780 ms with 16-line tiles, 0.795 with 24, 0.814 with 32
-    switch (rr) {
-    case 16: return launch5<S, UM, RESID, ZERO, 16>(a, st);
-    case 24: return launch5<S, UM, RESID, ZERO, 24>(a, st);
-    default: return launch5<S, UM, RESID, ZERO, 32>(a, st);
-    }
+    if (tile_rows_for(a) == 16) return launch5<S, UM, RESID, ZERO, 16, PROL, REST>(a, st);
+    return launch5<S, UM, RESID, ZERO, 32, PROL, REST>(a, st);
 }
 
 template <unsigned UM>
 int launch_prol(TArgs a, int sweeps, hipStream_t st)
 {
-    // (16-line tiles: measured best at every size)
     switch (sweeps) {
-    case 1: return launch5<1, UM, false, false, 16, true>(a, st);
-    case 2: return launch5<2, UM, false, false, 16, true>(a, st);
-    default: return launch5<3, UM, false, false, 16, true>(a, st);
+    case 1: return launch4<1, UM, false, false, true>(a, st);
+    case 2: return launch4<2, UM, false, false, true>(a, st);
+    default: return launch4<3, UM, false, false, true>(a, st);
     }
 }
 
@@ -354,9 +354,9 @@ template <unsigned UM>
 int launch_rest(TArgs a, int sweeps, bool zero, hipStream_t st)
 {
     switch (sweeps) {
-    case 1: return zero ? launch5<1, UM, true, true, 16, false, true>(a, st) : launch5<1, UM, true, false, 16, false, true>(a, st);
-    case 2: return zero ? launch5<2, UM, true, true, 16, false, true>(a, st) : launch5<2, UM, true, false, 16, false, true>(a, st);
-    default: return zero ? launch5<3, UM, true, true, 16, false, true>(a, st) : launch5<3, UM, true, false, 16, false, true>(a, st);
+    case 1: return zero ? launch4<1, UM, true, true, false, true>(a, st) : launch4<1, UM, true, false, false, true>(a, st);
+    case 2: return zero ? launch4<2, UM, true, true, false, true>(a, st) : launch4<2, UM, true, false, false, true>(a, st);
+    default: return zero ? launch4<3, UM, true, true, false, true>(a, st) : launch4<3, UM, true, false, false, true>(a, st);
     }
 }
 
@@ -382,7 +382,7 @@ int launch1(TArgs a, int sweeps, bool resid, bool zero, hipStream_t st)
 int lmg_tile_tune_set(const char *key, int v)
 {
     if (strcmp(key, "tile_rows") == 0 || strcmp(key, "tile_rows_big") == 0) {
-        if (v != 0 && v != 16 && v != 24 && v != 32) return LMG_ERR_ARG;
+        if (v != 0 && v != 16 && v != 32) return LMG_ERR_ARG;
         (key[9] ? g_tile_rows_big : g_tile_rows) = v;
         return LMG_OK;
     }

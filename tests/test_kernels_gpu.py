@@ -1044,12 +1044,12 @@ def test_row_pattern_sweeps_bit_exact(name, variant, nt):
 
 @pytest.mark.parametrize("name", ["poisson2d_129", "poisson1d", "galerkin_9pt", "with_empty_and_diagless_rows",
                                   "poisson2d_300"])
-@pytest.mark.parametrize("seg_lines,pf", [(0, 0), (4, 2), (7, 3), (1000, 2), ("tile", 16), ("tile", 24), ("tile", 32)])
+@pytest.mark.parametrize("seg_lines,pf", [(0, 0), (4, 2), (7, 3), (1000, 2), ("tile", 16), ("tile", 32)])
 def test_fused_stencil_smoothing_equals_separate_sweeps(name, seg_lines, pf):
     """lmg_stencil_smooth (S sweeps [+ residual] in one pass, iterates in registers) and lmg_stencil_smooth_tiled
     (the same with the iterates in LDS, what small levels run) against the oracle's separate Jacobi sweeps and
     residual, bitwise, for S = 1..3, zero / non-zero initial iterate, with and without the residual, few and many
-    line segments per strip / 16-, 24- and 32-line tiles."""
+    line segments per strip / 16- and 32-line tiles."""
     A = K.as_csr(P.poisson_2d_structured(299)[0]) if name == "poisson2d_300" else rpat_case(name)
     n = A.shape[0]
     dA = ops.DeviceCSR.from_scipy(A, DEV)

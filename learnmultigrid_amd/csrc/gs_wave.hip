@@ -30,6 +30,9 @@ namespace {
 
 constexpr int kMaxPat = 64;
 constexpr int kPF = 5;                      // iterations (of two steps) between issuing a load and using its value
+#ifndef LMG_GS_HYST
+#define LMG_GS_HYST 2          // (8: 8.12 ms per sweep at 4097^2, 4: 7.66, 2: 7.57; 513^2: 0.93 / 0.85 / 0.82)
+#endif
 constexpr int kPubDelay = 6;                // iterations between a result store and the progress that covers it: the
                                             // counted wait in front of the progress store also covers every LOAD issued
                                             // before that store, so it must not be shorter than the prefetch distance
@@ -129,7 +132,7 @@ __global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
         // Caught up with the previous band: wait until it is comfortably ahead (or done), not just one column --
         // a band that trails by exactly the dependency distance would come back here every iteration and advance
         // at one memory round trip per iteration (measured: 1.5 us instead of 0.3)
-        need = min(W, need + 8 * kPF);
+        need = min(W, need + LMG_GS_HYST * kPF);
         // (bounded: the previous band holds an earlier ticket, so it is running or done and its counter only
         // grows; the budget -- a few seconds per band in total -- turns a protocol bug into a wrong result with
         // an error flag instead of a hung GPU)

@@ -355,8 +355,10 @@ int lmg_csr_gs_schedule_ell(int64_t n, const double *d_vals, double *d_x, const 
  * ops.StencilTwin.gs_ok): union_mask accepted by lmg_stencil_gs_supported (5-, 7-, 9-point, 1-D), and no
  * pattern used in column 0 / line_stride-1 of a line couples across the line end.  hot_pattern /
  * h_hot_val as in lmg_stencil_smooth (steps in which every lane relaxes that pattern skip the LDS table).  d_work:
- * lmg_stencil_gs_work_bytes(n, line_stride) bytes, 8-byte aligned, its last int32 zeroed by the caller
- * once (it is set when a band had to give up waiting: the result is then invalid). */
+ * lmg_stencil_gs_work_bytes(n, line_stride) bytes, 8-byte aligned, its FIRST int32 zeroed by the caller
+ * once (it is set when a band had to give up waiting: the result is then invalid).  Up to four sweeps share
+ * one launch, pipelined behind each other (band b of sweep s trails band b + 1 of sweep s - 1), so the
+ * pipeline fill -- 64 SK steps per band -- is paid once per launch, not once per sweep. */
 int lmg_stencil_gs_supported(uint32_t union_mask);
 int64_t lmg_stencil_gs_work_bytes(int64_t n, int32_t line_stride);
 int lmg_stencil_gs_sweep(int64_t n, int32_t line_stride, const uint8_t *d_pid, int32_t npat,

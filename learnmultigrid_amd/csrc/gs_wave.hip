@@ -36,7 +36,9 @@ constexpr int kPF = 5;                      // iterations (of two steps) between
 constexpr int kPubDelay = 6;                // iterations between a result store and the progress that covers it: the
                                             // counted wait in front of the progress store also covers every LOAD issued
                                             // before that store, so it must not be shorter than the prefetch distance
-constexpr int kVmOpsPerIter = 11;           // vector-memory instructions per iteration: 6 loads, 2 + 2 result stores, progress
+constexpr int kVmOpsBase = 11;              // vector-memory instructions per iteration: 6 loads, 2 + 2 result stores, progress
+                                            // (+ 1 load with several sweeps per launch)
+constexpr int kMaxSweeps = 4;               // sweeps pipelined behind each other in one launch
 constexpr unsigned kMask5 = 0x0BAu, kMask9 = 0x1FFu, kMask7 = 0x1BBu, kMask1D = 0x038u;
 constexpr unsigned kOOB = 0xFFFFFFF0u;      // buffer offset beyond any num_records: the access is dropped / reads 0
 constexpr int kSc1 = 16;                    // buffer cache policy: sc1 (write-through / L1 bypass, agent scope)
@@ -53,8 +55,9 @@ struct GArgs {
     const double *b;
     int hot;                                // interior pattern (all union slots, non-zero diagonal) or -1
     double hot_val[9];
-    int *work;                              // [0] ticket, [1 + k] columns done on the last line of band k,
-                                            // [1 + nbands] where the other lanes "publish", [2 + nbands] error flag
+    int sweeps;                             // sweeps of this launch (<= kMaxSweeps), pipelined: see gs_wavefront_kernel
+    int *work;                              // [0] error flag, [1] ticket, [2] where the other lanes "publish",
+                                            // [3 + s * nbands + k] columns done on the last line of band k in sweep s
 };
 
 __device__ __forceinline__ double dpp_lower(double src)      // lane i <- lane i-1, lane 0 <- 0
@@ -77,31 +80,45 @@ __device__ __forceinline__ unsigned pair_off(int64_t i, int n)
 
 struct Ahead {          // what iteration it + kPF needs (two columns), on its way through memory
     u4 own, down, up, b;
-    int pid2, flag;
+    int pid2, flag, flag_old;
 };
 
-template <unsigned UM>
+// MULTI: several sweeps in ONE launch, pipelined behind each other.  Tickets run over (sweep, band) in row-major order;
+// band b of sweep s additionally trails band b + 1 of sweep s - 1 (the last band: band b itself): once that one has
+// finished columns <= c on ALL its lines, the old values this band reads there -- its own lines and the line below --
+// are the previous sweep's final ones, and nobody will read what this band overwrites.  Both dependencies hold
+// smaller tickets, so a band only ever waits for bands that are running or done.  The pipeline fill (64 * SK steps per
+// band, two thirds of a sweep at 4097^2) is paid once per launch instead of once per sweep.  All result stores are
+// write-through and all loads of x bypass the caches in this mode (other workgroups read / wrote them in this launch).
+template <unsigned UM, bool MULTI>
 __global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
 {
     constexpr int SK = (UM & 4u) ? 2 : 1;
+    constexpr int kXPol = MULTI ? kSc1 : 0;                       // cache policy of the loads of x
     __shared__ double s_val[kMaxPat * 9];
     __shared__ int s_mask[kMaxPat];
     __shared__ int s_band;
     const int lane = threadIdx.x;
     for (int i = lane; i < a.npat * 9; i += 64) s_val[i] = a.st_val[i];
     for (int i = lane; i < a.npat; i += 64) s_mask[i] = a.st_mask[i];
-    if (lane == 0) s_band = atomicAdd(&a.work[0], 1);
+    if (lane == 0) s_band = atomicAdd(&a.work[1], 1);
     __syncthreads();
-    const int band = __builtin_amdgcn_readfirstlane(s_band);
-    if (band >= a.nbands) return;
+    const int ticket = __builtin_amdgcn_readfirstlane(s_band);
+    if (ticket >= a.nbands * a.sweeps) return;
+    const int sweep = ticket / a.nbands, band = ticket - sweep * a.nbands;
 
     const int n = a.n, W = a.W;
     const int y = band * 64 + lane;
     const bool line_ok = y < a.lines;
     const int64_t base = (int64_t)y * W;
     const int last_lane = min(63, a.lines - 1 - band * 64);          // lane of the band's last line
-    int *prog_mine = a.work + 1 + (lane == last_lane ? band : a.nbands);      // other lanes: a dummy word
-    const int *prog_prev = a.work + (band > 0 ? band : 0);            // band 0 reads the ticket word and ignores it
+    int *const prog = a.work + 3 + sweep * a.nbands;
+    int *prog_mine = lane == last_lane ? prog + band : a.work + 2;    // other lanes: a dummy word
+    // (counters that are read but ignored point at the error flag, a word nobody writes: the dummy word [2] is
+    // stored to by every wave in every iteration, and a load behind that traffic holds up the in-order vmcnt)
+    const int *prog_prev = band > 0 ? prog + band - 1 : a.work;
+    const bool has_old = MULTI && sweep > 0;
+    const int *prog_old = has_old ? prog - a.nbands + min(band + 1, a.nbands - 1) : a.work;
     const int ITER = (W + SK * 63 + 1) / 2 + 1;                       // iterations of a band (two steps each)
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a.x, 0, (int)((unsigned)n * 8u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void *)a.b, 0, (int)((unsigned)n * 8u), 0x00020000);
@@ -111,8 +128,8 @@ __global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
     auto fetch = [&](int itf, Ahead &A) {
         const int xf = 2 * itf - SK * lane;
         const int64_t i = base + xf;
-        A.own = __builtin_amdgcn_raw_buffer_load_b128(rs_x, pair_off(i + 1, n), 0, 0);          // old (y, xf+1), (y, xf+2)
-        A.down = __builtin_amdgcn_raw_buffer_load_b128(rs_x, pair_off(i + W + 1, n), 0, 0);     // old (y+1, xf+1), (y+1, xf+2)
+        A.own = __builtin_amdgcn_raw_buffer_load_b128(rs_x, pair_off(i + 1, n), 0, kXPol);      // old (y, xf+1), (y, xf+2)
+        A.down = __builtin_amdgcn_raw_buffer_load_b128(rs_x, pair_off(i + W + 1, n), 0, kXPol); // old (y+1, xf+1), (y+1, xf+2)
         A.b = __builtin_amdgcn_raw_buffer_load_b128(rs_b, pair_off(i, n), 0, 0);
         {
             const int64_t j = i + (i == -1 ? 1 : 0) - (i == (int64_t)n - 1 ? 1 : 0);
@@ -121,12 +138,11 @@ __global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
         // lane 0: new (y-1, xf+SK-1), (y-1, xf+SK) of the previous band, write-through data -> L1 bypass
         A.up = __builtin_amdgcn_raw_buffer_load_b128(rs_x, lane == 0 ? pair_off(i - W + (SK - 1), n) : kOOB, 0, kSc1);
         A.flag = __hip_atomic_load(prog_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        A.flag_old = MULTI ? __hip_atomic_load(prog_old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     };
     // lane 0's read of the line above is only legal once the previous band has published those columns
     int spin_budget = 1 << 22;
-    auto wait_for_prev = [&](int itf, int flag_seen) {
-        if (band == 0) return;
-        int need = min(W, 2 * itf + SK + 1);                          // columns 0 .. 2 itf + SK done
+    auto wait_for = [&](const int *counter, int need, int flag_seen) {
         int f = __builtin_amdgcn_readfirstlane(flag_seen);
         if (f >= need) return;
         // Caught up with the previous band: wait until it is comfortably ahead (or done), not just one column --
@@ -139,9 +155,15 @@ __global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
         while (f < need && spin_budget > 0) {
             --spin_budget;
             __builtin_amdgcn_s_sleep(2);
-            f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(prog_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
-        if (f < need && lane == 0) a.work[2 + a.nbands] = 1;
+        if (f < need && lane == 0) a.work[0] = 1;
+    };
+    auto wait_for_prev = [&](int itf, int flag_seen, int flag_old_seen) {
+        // the line above: columns 0 .. 2 itf + SK of the previous band done
+        if (band > 0) wait_for(prog_prev, min(W, 2 * itf + SK + 1), flag_seen);
+        // the previous sweep: columns 0 .. 2 itf + 2 of this band's lines and of the line below final
+        if (has_old) wait_for(prog_old, min(W, 2 * itf + 3), flag_old_seen);
     };
 
     double U0 = 0.0, U1 = 0.0, U2 = 0.0;      // new values of the line above at columns x-1, x, x+1
@@ -149,11 +171,11 @@ __global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
     double O0 = 0.0, O1 = 0.0;                // old values of the own line at columns x, x+1
     double R = 0.0;                           // own result of the previous step = new (y, x-1)
     Ahead ring[kPF];
-    int flag_seen = 0;
+    int flag_seen = 0, flag_old_seen = 0;
     // prologue: the first kPF iterations' loads (lane 0's line-above loads need the previous band first)
 #pragma unroll
     for (int u = 0; u < kPF; ++u) {
-        wait_for_prev(u, flag_seen);
+        wait_for_prev(u, flag_seen, flag_old_seen);
         fetch(u, ring[u]);
     }
     {   // windows just before the first step (column x0 = -SK lane): what the first shift moves into place
@@ -232,6 +254,7 @@ __global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
             const int x = 2 * it - SK * lane;             // columns x, x + 1 in this iteration
             const Ahead cur = ring[u];
             flag_seen = cur.flag;
+            flag_old_seen = cur.flag_old;
             const int64_t i = base + x;
             // which half of a pair is which (only the pairs straddling element 0 / n-1 are special)
             auto first = [&](const u4 &v, int64_t ii) { return ii == (int64_t)n - 1 ? hi2(v) : lo2(v); };
@@ -239,7 +262,7 @@ __global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
             const int pa = (i == (int64_t)n - 1) ? (cur.pid2 >> 8) & 0xff : cur.pid2 & 0xff;
             const int pb = (i == -1) ? cur.pid2 & 0xff : (cur.pid2 >> 8) & 0xff;
             // ---- next loads ----------------------------------------------------------------------------
-            wait_for_prev(it + kPF, flag_seen);
+            wait_for_prev(it + kPF, flag_seen, flag_old_seen);
             fetch(it + kPF, ring[u]);
             // ---- two steps -----------------------------------------------------------------------------
             // (the wave shifts run with all lanes enabled: a DPP read from a lane that a branch has switched off
@@ -255,7 +278,7 @@ __global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
             // (sc1) -- 64 write-through lines per instruction cost 2 us per iteration (SQ_WAIT_ANY 70 %: every later
             // load is counted behind them in vmcnt); all other lanes use plain stores, flushed at the kernel boundary.
             const bool actA = line_ok && x >= 0 && x < W && i < n, actB = line_ok && x + 1 >= 0 && x + 1 < W && i + 1 < n;
-            const bool shared = lane == last_lane;
+            const bool shared = MULTI || lane == last_lane;
             u4 v4;
             v4.x = (unsigned)__double2loint(xa);
             v4.y = (unsigned)__double2hiint(xa);
@@ -272,6 +295,7 @@ __global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
             __builtin_amdgcn_raw_buffer_store_b64(v2, rs_x, shared ? off8 : kOOB, 0, kSc1);
             // ---- publish: the result stores of kPubDelay iterations ago have completed ----------------------
             {
+                constexpr int kVmOpsPerIter = kVmOpsBase + (MULTI ? 1 : 0);
                 constexpr int N = kVmOpsPerIter * (kPubDelay - 1);
                 static_assert(N < 64 && kVmOpsPerIter * kPF < 64, "vmcnt range");
                 __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
@@ -289,12 +313,39 @@ __global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
 template <unsigned UM>
 int launch(GArgs a, hipStream_t st)
 {
-    hipLaunchKernelGGL((gs_wavefront_kernel<UM>), dim3((unsigned)a.nbands), dim3(64), 0, st, a);
+    if (a.sweeps > 1)
+        hipLaunchKernelGGL((gs_wavefront_kernel<UM, true>), dim3((unsigned)(a.nbands * a.sweeps)), dim3(64), 0, st, a);
+    else
+        hipLaunchKernelGGL((gs_wavefront_kernel<UM, false>), dim3((unsigned)a.nbands), dim3(64), 0, st, a);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }
 
+int g_gs_max_sweeps = kMaxSweeps;           // sweeps pipelined in one launch (1 = a launch per sweep)
+int g_gs_multi_max_rows = 8000000;          // ... on levels of at most this many rows
+
 }  // namespace
+
+int lmg_gsw_tune_set(const char *key, int v)
+{
+    if (strcmp(key, "gsw_max_sweeps") == 0) {
+        if (v < 1 || v > kMaxSweeps) return LMG_ERR_ARG;
+        g_gs_max_sweeps = v;
+        return LMG_OK;
+    }
+    if (strcmp(key, "gsw_multi_max_rows") == 0) {
+        if (v < 0) return LMG_ERR_ARG;
+        g_gs_multi_max_rows = v;
+        return LMG_OK;
+    }
+    return LMG_ERR_ARG;
+}
+int lmg_gsw_tune_get(const char *key)
+{
+    if (strcmp(key, "gsw_max_sweeps") == 0) return g_gs_max_sweeps;
+    if (strcmp(key, "gsw_multi_max_rows") == 0) return g_gs_multi_max_rows;
+    return LMG_ERR_ARG;
+}
 
 extern "C" {
 
@@ -307,7 +358,7 @@ int64_t lmg_stencil_gs_work_bytes(int64_t n, int32_t line_stride)
 {
     if (n <= 0 || line_stride <= 0) return 0;
     const int64_t lines = (n + line_stride - 1) / line_stride, nbands = (lines + 63) / 64;
-    return 4 * (nbands + 3) + 4;
+    return 4 * (kMaxSweeps * nbands + 3) + 4;
 }
 
 int lmg_stencil_gs_sweep(int64_t n, int32_t line_stride, const uint8_t *pid, int32_t npat, const double *st_val,
@@ -338,10 +389,16 @@ int lmg_stencil_gs_sweep(int64_t n, int32_t line_stride, const uint8_t *pid, int
         for (int k = 0; k < 9; ++k) a.hot_val[k] = h_hot_val[k];
     }
     hipStream_t st = lmg_stream(stream);
-    for (int sw = 0; sw < sweeps; ++sw) {
+    a.sweeps = 1;
+    for (int sw = 0; sw < sweeps; sw += a.sweeps) {
+        // several sweeps per launch only while the level lives in the Infinity Cache: their loads of x bypass L2 (16 bytes
+        // per lane and iteration straight from memory), which costs more than the saved pipeline fills beyond it
+        // (3 sweeps: 513^2 1.19 vs 2.43 ms, 1025^2 2.40 vs 4.80, 2049^2 7.2 vs 10.4, 3073^2 15.1 vs 16.0, 4097^2 26.8 vs 22.4)
+        const int per_launch = n <= g_gs_multi_max_rows ? g_gs_max_sweeps : 1;
+        a.sweeps = sweeps - sw < per_launch ? sweeps - sw : per_launch;
         // ticket and progress counters back to zero (a memset node when captured into a hipGraph)
-        // (the error flag at [2 + nbands] is cleared by the caller once and stays set)
-        if (hipMemsetAsync(a.work, 0, 4 * (size_t)(a.nbands + 2), st) != hipSuccess) return LMG_ERR_LAUNCH;
+        // (the error flag at [0] is cleared by the caller once and stays set)
+        if (hipMemsetAsync(a.work + 1, 0, 4 * (size_t)(a.sweeps * a.nbands + 2), st) != hipSuccess) return LMG_ERR_LAUNCH;
         int rc;
         switch (union_mask) {
         case kMask5: rc = launch<kMask5>(a, st); break;

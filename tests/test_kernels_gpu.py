@@ -213,6 +213,36 @@ def test_wavefront_gauss_seidel_bit_exact(name):
         ops.set_wavefront_gs_enabled(True)
 
 
+@pytest.mark.parametrize("m,kind", [(1024, "5pt"), (640, "9pt")])
+def test_wavefront_gauss_seidel_sweeps_pipelined_in_one_launch(m, kind):
+    """Several sweeps in ONE launch (band b of sweep s trails band b + 1 of sweep s - 1) against the oracle and against
+    one launch per sweep, bitwise: 7 sweeps (chunks of 4 + 3) on 17 / 11 bands."""
+    if kind == "5pt":
+        A = K.as_csr(P.poisson_2d_structured(m)[0])
+    else:
+        Pm = P.tensor_interpolator_2d(2 * m + 1)
+        A = K.as_csr(sp.csr_matrix(Pm.T @ P.poisson_2d_structured(2 * m)[0] @ Pm))
+    n = A.shape[0]
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    dA.pack()
+    assert ops.stencil_gs_available(dA) and ops.tune_get("gsw_max_sweeps") == 4 and n <= ops.tune_get("gsw_multi_max_rows")
+    rng = np.random.default_rng(8)
+    x0, b = rng.standard_normal(n), rng.standard_normal(n)
+    want = x0.copy()
+    K.lib().orc_csr_gs_forward(n, A.indptr, A.indices, A.data, want, b, 7)
+    x = dev(x0.copy())
+    ops.stencil_gs(dA, x, dev(b), 7)
+    ops.stencil_gs_check(dA)
+    assert np.array_equal(x.cpu().numpy(), want)
+    try:
+        ops.tune_set("gsw_max_sweeps", 1)
+        x1 = dev(x0.copy())
+        ops.stencil_gs(dA, x1, dev(b), 7)
+        assert torch.equal(x1, x)
+    finally:
+        ops.tune_set("gsw_max_sweeps", 4)
+
+
 def test_wavefront_gauss_seidel_leaves_chains_to_the_chain_executor():
     dA = ops.DeviceCSR.from_scipy(rpat_case("poisson1d"), DEV)
     dA.pack()

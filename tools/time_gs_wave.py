@@ -26,7 +26,16 @@ for m in [int(v) for v in a.sizes.split(",")]:
         t0 = time.perf_counter()
         for _ in range(reps): ops.stencil_gs(dA, x, b, 1)
         torch.cuda.synchronize(); tw = (time.perf_counter() - t0) / reps
-        msg = "%s: wavefront %.3f ms/sweep" % (lab, tw * 1e3)
+        t0 = time.perf_counter()
+        for _ in range(reps): ops.stencil_gs(dA, x, b, 3)
+        torch.cuda.synchronize(); tw3 = (time.perf_counter() - t0) / reps
+        ops.tune_set("gsw_max_sweeps", 1)
+        t0 = time.perf_counter()
+        for _ in range(reps): ops.stencil_gs(dA, x, b, 3)
+        torch.cuda.synchronize(); tw3s = (time.perf_counter() - t0) / reps
+        ops.tune_set("gsw_max_sweeps", 4)
+        ops.stencil_gs_check(dA)
+        msg = "%s: wavefront %.3f ms/sweep; 3 sweeps pipelined in one launch %.3f ms (one launch each: %.3f ms)" % (lab, tw * 1e3, tw3 * 1e3, tw3s * 1e3)
         if a.level or m <= 1024:
             pat = sp.csr_matrix((np.ones(M.nnz, dtype=np.int8), M.indices, M.indptr), shape=M.shape)
             sched = ops.build_gs_schedule(pat, "lexicographic", "cuda:0")

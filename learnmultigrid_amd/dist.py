@@ -387,9 +387,17 @@ class DistributedVCycle:
                                 (nrows, d.n_tot))
                 d.P = DeviceCSR(rp_ploc, ci_ploc.contiguous(), va_ploc, (d.n_tot, full.levels[l + 1].n))
         if getattr(full, "use_packed", False):
-            for d in self.dl:
-                for M in (d.A, d.R, d.P):
-                    M.pack()
+            for l, d in enumerate(self.dl):
+                d.A.pack()
+                # local blocks are whole grid lines: their transfers are grid transfers with these line lengths
+                # (row patterns relative to a column-base map instead of a packed CSR stream)
+                wf, wc = math.isqrt(sizes[l]), math.isqrt(sizes[l + 1])
+                hint = (wf, wc) if (side is not None and wf * wf == sizes[l] and wc * wc == sizes[l + 1]) else None
+                for M in (d.R, d.P):
+                    try:
+                        M.pack(line_strides=hint)
+                    except TypeError:                     # (an ops module without the hint: tests' CPU shim)
+                        M.pack()
         # ---- all-gather plumbing for the first replicated level ----------------------------------
         L = self.n_dist
         cb = self.bounds[L]

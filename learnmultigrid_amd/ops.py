@@ -55,10 +55,11 @@ class DeviceCSR:
         self.prolong = None          # ProlongTwin view of `patterns` (2x2-window grid prolongations)
         self.restrict = None         # RestrictTwin view of `patterns` (their transposes)
 
-    def pack(self, patterns=None):
+    def pack(self, patterns=None, line_strides=None):
         """Build (once) the lossless twin the sweep kernels prefer; keeps the CSR arrays.
         Row patterns (RowPatterns) when the rows repeat -- assembled grid operators --, else the
-        packed CSR (PackedCSR).  patterns=False forces the packed CSR, None = module default."""
+        packed CSR (PackedCSR).  patterns=False forces the packed CSR, None = module default.
+        line_strides: see RowPatterns.grid_map_candidates (transfers between non-square blocks of grid lines)."""
         if not self.vals.is_cuda:
             return None
         if patterns is None:
@@ -68,7 +69,7 @@ class DeviceCSR:
                 self.patterns = RowPatterns.from_csr(self)
             else:
                 # rectangular grid operators (transfers): row patterns relative to a column-base map
-                for gm in (RowPatterns.grid_map_candidates(self.shape) if _GRID_MAPS_ENABLED else []):
+                for gm in (RowPatterns.grid_map_candidates(self.shape, line_strides) if _GRID_MAPS_ENABLED else []):
                     self.patterns = RowPatterns.from_csr(self, gm)
                     if self.patterns is not None:
                         break
@@ -378,14 +379,20 @@ class RowPatterns:
                  "grid_map", "_gm")
 
     @staticmethod
-    def grid_map_candidates(shape):
+    def grid_map_candidates(shape, line_strides=None):
         """Column-base maps worth trying for a RECTANGULAR operator (see lmg_rpat_sweep_grid): the
         tensor-product transfer between two square grids when both dimensions are perfect squares, and
-        the 1-D transfer.  Nothing is assumed: a map is only used if every entry verifies."""
+        the 1-D transfer.  line_strides = (fine, coarse) line lengths of a transfer between blocks of whole grid
+        lines that are not square (the local blocks of a distributed level): tried first.  Nothing is assumed: a
+        map is only used if every entry verifies."""
         nr, nc = int(shape[0]), int(shape[1])
         if nr == nc or nr < 2 or nc < 2:
             return []
         out = []
+        if line_strides is not None:
+            wf, wcs = int(line_strides[0]), int(line_strides[1])
+            if wf >= 2 and wcs >= 2:
+                out.append((wf, wcs, 1, 1, 0) if nr > nc else (wcs, 2 * wf, 0, 0, 1))
         wr, wc = math.isqrt(nr), math.isqrt(nc)
         if wr * wr == nr and wc * wc == nc and min(wr, wc) >= 2:
             out.append((wr, wc, 1, 1, 0) if nr > nc else (wr, 2 * wc, 0, 0, 1))

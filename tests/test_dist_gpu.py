@@ -56,6 +56,7 @@ def test_world1_nccl_path_matches_single_gpu_bitwise():
 
 
 def _gpu_worker(rank, world, port, out_dir, transfer="geometric", fuse_all=False):
+    import math
     import os
     import sys
     import torch.distributed as dist
@@ -86,11 +87,13 @@ def _gpu_worker(rank, world, port, out_dir, transfer="geometric", fuse_all=False
         assert D.host_staged and D.n_dist == 2
         if transfer == "geometric":
             # local operators run on their lossless twins: row patterns for the square grid operators
-            # (ghost rows are one more pattern); the transfers on 16-bit packed columns, or -- local blocks of
-            # few grid lines -- on row patterns relative to the 1-D column map (verified entry by entry)
+            # (ghost rows are one more pattern) and for the transfers, relative to the column-base map of the
+            # local blocks' line lengths (verified entry by entry)
             assert all(d.A.patterns is not None for d in D.dl)
-            assert all((M.packed is not None and M.packed.colmode == 0) or M.patterns is not None
-                       for d in D.dl for M in (d.R, d.P))
+            for l, d in enumerate(D.dl):
+                wf, wc = math.isqrt(D.full.levels[l].n), math.isqrt(D.full.levels[l + 1].n)
+                assert d.P.patterns is not None and d.P.patterns.grid_map == (wf, wc, 1, 1, 0), (l, d.P.patterns)
+                assert d.R.patterns is not None and d.R.patterns.grid_map == (wc, 2 * wf, 0, 0, 1), (l, d.R.patterns)
         else:
             # 25-entry Galerkin rows and restrictions with all-distinct values: sliced ELL
             assert D.dl[1].A.sell is not None and D.dl[0].R.sell is not None

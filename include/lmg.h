@@ -429,6 +429,10 @@ int lmg_coarse_front(int64_t nblocks, int64_t bs, const double *d_M, const doubl
 int lmg_coarse_back(int64_t nblocks, int64_t rows, int64_t cols, const double *d_M, const double *d_x,
                     const int32_t *d_x_offsets, const double *d_z, int64_t z_stride, double alpha, const int32_t *d_perm,
                     double *d_out, int accumulate, int64_t ntail, void *stream);
+
+/* Setup helper: d_counts[((y & 1) * 2 + (x & 1)) * 256 + id] += number of rows i = y * line_stride + x with pattern id
+ * d_pid[i] = id (d_counts: 1024 int32, zeroed by the caller). */
+int lmg_pattern_parity_counts(int64_t n, int32_t line_stride, const uint8_t *d_pid, int32_t *d_counts, void *stream);
 int lmg_block_copy(int64_t nblocks, int64_t bs, const double *d_src, int64_t src_stride, double *d_dst,
                    int64_t dst_stride, void *stream);
 

@@ -283,6 +283,23 @@ __global__ void __launch_bounds__(kBlock) coarse_back_kernel(int64_t nb, int64_t
     }
 }
 
+// How often every pattern id occurs on (even / odd line) x (even / odd column) of a grid with line stride W:
+// counts[((y & 1) * 2 + (x & 1)) * 256 + id] (zeroed by the caller).  Setup helper of ops.ProlongTwin (a library
+// histogram costs 0.4 s of code-object loading in a fresh process).
+__global__ void __launch_bounds__(kBlock) pattern_parity_counts_kernel(int64_t n, int W, const unsigned char *pid, int *counts)
+{
+    __shared__ int s_cnt[4 * 256];
+    for (int i = threadIdx.x; i < 4 * 256; i += kBlock) s_cnt[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const unsigned y = (unsigned)(i / W), x = (unsigned)(i - (int64_t)y * W);
+        atomicAdd(&s_cnt[(((y & 1u) << 1) | (x & 1u)) * 256 + pid[i]], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * 256; i += kBlock)
+        if (s_cnt[i]) atomicAdd(&counts[i], s_cnt[i]);
+}
+
 // dense[i][colidx[e]] += vals[e] for the entries e of row i (dense zero-initialised by the caller)
 __global__ void __launch_bounds__(kBlock) csr_to_dense_kernel(int64_t n, int64_t m, const int *rowptr, const int *colidx,
                                                               const double *vals, double *dense)
@@ -670,6 +687,16 @@ int lmg_coarse_back(int64_t nblocks, int64_t rows, int64_t cols, const double *M
     hipLaunchKernelGGL(coarse_back_kernel, dim3(grid_for(nblocks * rows > 0 ? nblocks * rows : 1, kBlock / LMG_WAVE)), dim3(kBlock), 0,
                        lmg_stream(stream), nblocks, rows, cols, M, x, x_offsets, z, z_stride, alpha, perm, out, accumulate,
                        ntail);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_pattern_parity_counts(int64_t n, int32_t line_stride, const uint8_t *pid, int32_t *counts, void *stream)
+{
+    if (n < 0 || line_stride < 1 || (n > 0 && (!pid || !counts))) return LMG_ERR_ARG;
+    if (n == 0) return LMG_OK;
+    hipLaunchKernelGGL(pattern_parity_counts_kernel, dim3(grid_for(n, kBlock * 16)), dim3(kBlock), 0, lmg_stream(stream), n,
+                       line_stride, pid, counts);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }

@@ -368,6 +368,14 @@ class SellCSR:
         return True
 
 
+def _pid_counts(R):
+    """How often every pattern id of a RowPatterns twin occurs (own histogram kernel: a library one costs 0.4 s of
+    code-object loading in a fresh process)."""
+    cnt = torch.zeros(4 * 256, dtype=I32, device=R.pid.device)
+    check(_lib.lib().lmg_pattern_parity_counts(int(R.n), 1, _p(R.pid), _p(cnt), _s()), "lmg_pattern_parity_counts")
+    return cnt.cpu().numpy().reshape(4, 256).sum(axis=0)[:R.npat].astype(np.int64)
+
+
 class RowPatterns:
     """Lossless row-pattern twin of a DeviceCSR for lmg_rpat_sweep (see include/lmg.h): every
     distinct row -- (length; column - row and value bits of each entry, in storage order) -- is
@@ -538,7 +546,7 @@ class StencilTwin:
         self.hot, self._hot_val = -1, None
         cand = [p for p in range(R.npat) if st_mask[p] == self.umask and (st_mask[p] & 16) and st_val[p * 9 + 4] != 0.0]
         if cand:
-            counts = torch.bincount(R.pid.long(), minlength=R.npat).cpu().numpy() if len(cand) > 1 else None
+            counts = _pid_counts(R) if len(cand) > 1 else None
             self.hot = int(cand[0] if counts is None else max(cand, key=lambda p: counts[p]))
             self._hot_val = (ctypes.c_double * 9)(*[float(v) for v in st_val[self.hot * 9: self.hot * 9 + 9]])
         # wavefront Gauss-Seidel (lmg_stencil_gs_sweep) needs a supported slot set and no coupling across the
@@ -592,12 +600,9 @@ class ProlongTwin:
         dev = R.pid.device
         # which patterns occur where: counts by (line parity, column parity)
         n = int(R.n)
-        rows = torch.arange(n, dtype=torch.int32, device=dev)
-        yp = torch.div(rows, W, rounding_mode="floor") & 1
-        xp = (rows - torch.div(rows, W, rounding_mode="floor") * W) & 1
-        key = (yp * 2 + xp).long() * R.npat + R.pid.long()
-        counts = torch.bincount(key, minlength=4 * R.npat).cpu().numpy().reshape(2, 2, R.npat)
-        del rows, yp, xp, key
+        cnt = torch.zeros(4 * 256, dtype=I32, device=dev)
+        check(_lib.lib().lmg_pattern_parity_counts(n, int(W), _p(R.pid), _p(cnt), _s()), "lmg_pattern_parity_counts")
+        counts = cnt.cpu().numpy().reshape(2, 2, 256)[:, :, :R.npat].astype(np.int64)
         if np.any((counts[0].sum(axis=0) > 0) & ((p_mask & 0xC) != 0)):
             return None                        # a row on an even line reaching the coarse line below: not this shape
         self = cls()
@@ -669,7 +674,7 @@ class RestrictTwin:
         self.hot, self._hot_val = -1, None
         cand = [p for p in range(R.npat) if r_mask[p] == 0x1FF]
         if cand:
-            counts = torch.bincount(R.pid.long(), minlength=R.npat).cpu().numpy() if len(cand) > 1 else None
+            counts = _pid_counts(R) if len(cand) > 1 else None
             self.hot = int(cand[0] if counts is None else max(cand, key=lambda p: counts[p]))
             self._hot_val = (ctypes.c_double * 9)(*[float(v) for v in r_val[self.hot * 9: self.hot * 9 + 9]])
         return self

@@ -3,7 +3,7 @@
 V(3,3) cycle once per setting and times the replays round-robin (a stand-alone timing loop and a different
 gpurun box have both pointed the wrong way before; see csrc/stencil_fused.hip).
 
-  python tools/ab_cycle.py --set base --set fused_pf=3 --set fused_seg_lines=24 --set py:FUSED_MIN_ROWS=1000000
+  python tools/ab_cycle.py --set base --set fused_seg_lines=24 --set py:FUSED_MIN_ROWS=1000000
 Settings: `key=value[,key=value...]` for ops.tune_set keys, `py:NAME=value` / `coarse:NAME=value` for module
 constants of ops / coarse.
 """

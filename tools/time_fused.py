@@ -7,7 +7,7 @@ from learnmultigrid_amd import ops, problems as P
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=4096)
 ap.add_argument("--seg", default="0")
-ap.add_argument("--pf", default="2,3")
+ap.add_argument("--pf", default="2")
 a = ap.parse_args()
 ops.FUSED_MIN_ROWS = 0          # time the fused pass at every size
 cases = []

@@ -36,6 +36,8 @@ __device__ __forceinline__ double dpp_upper(double src)      // lane i <- lane i
     return __hiloint2double(hi, lo);
 }
 
+struct __attribute__((aligned(8))) d2u { double a, b; };
+
 struct TArgs {
     int n, W, lines, npat;
     int tiles_x, tiles_y;
@@ -112,15 +114,28 @@ __global__ void __launch_bounds__(RR / kRB * LMG_WAVE) stencil_tile_kernel(TArgs
         pk[k] = ok ? ((int)a.pid[j] | 0x100) : 0;
         if (PROL) {
             // the element is row j of P whatever its place in the tile (a column outside [0, W) is an element of the
-            // adjacent line): its own line and column decide the window
-            const unsigned yy = (unsigned)j / (unsigned)a.W, xx = (unsigned)j - yy * (unsigned)a.W;
+            // adjacent line): its own line and column decide the window.  On grids at least two tiles wide one step to
+            // the neighbouring line is enough; narrower ones divide.
+            const int c = c0 + lane;
+            int yy, xx;
+            if (a.W >= 2 * kCols) {                               // uniform
+                yy = c < 0 ? y - 1 : (c >= a.W ? y + 1 : y);
+                xx = c < 0 ? c + a.W : (c >= a.W ? c - a.W : c);
+            } else {
+                yy = (int)((unsigned)j / (unsigned)a.W);
+                xx = (int)((unsigned)j - (unsigned)yy * (unsigned)a.W);
+            }
             const int64_t base = (int64_t)(yy >> 1) * a.Wc + (xx >> 1);
             lq[k] = ok ? (int)a.ppid[j] : 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t jc = base + (q & 1) + (q >> 1) * (int64_t)a.Wc;
-                le[k][q] = a.ec[jc < a.nc ? jc : a.nc - 1];       // (slots a pattern does not have may point anywhere)
-            }
+            // slots 0, 1 and 2, 3 are neighbours in memory: two 16-byte loads (8-byte aligned is enough); slots a
+            // pattern does not have may point anywhere inside the vector
+            const int64_t b0 = ok ? min(base, (int64_t)a.nc - 2) : 0, b1 = ok ? min(base + a.Wc, (int64_t)a.nc - 2) : 0;
+            const d2u e01 = *reinterpret_cast<const d2u *>(a.ec + b0), e23 = *reinterpret_cast<const d2u *>(a.ec + b1);
+            // (a window clamped at the end of the vector starts one element early: its first slot is the second value)
+            le[k][0] = b0 == base ? e01.a : e01.b;
+            le[k][1] = e01.b;
+            le[k][2] = b1 == base + a.Wc ? e23.a : e23.b;
+            le[k][3] = e23.b;
         }
         if (REST) {
             // elements on (even line, even column) of the grid carry a row of R
@@ -474,7 +489,7 @@ int lmg_stencil_smooth_tiled_prolong(int64_t n, int32_t line_stride, const uint8
                                      void *stream)
 {
     if (!x_in || !e_coarse || !p_pid || !p_val || !p_mask || p_npat < 1 || p_npat > kMaxPat) return LMG_ERR_ARG;
-    if (n_coarse < 1 || n_coarse >= (1ll << 31) || coarse_stride < 1 || coarse_stride > n_coarse) return LMG_ERR_ARG;
+    if (n_coarse < 2 || n_coarse >= (1ll << 31) || coarse_stride < 1 || coarse_stride > n_coarse) return LMG_ERR_ARG;
     if (e_coarse == x_out) return LMG_ERR_ARG;
     TArgs a;
     const int rc = tile_args(a, n, line_stride, pid, npat, st_val, st_mask, union_mask, hot_pattern, h_hot_val, sweeps, x_in, b,

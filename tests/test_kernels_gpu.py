@@ -1126,7 +1126,7 @@ def test_fused_stencil_smoothing_equals_separate_sweeps(name, seg_lines, pf):
         ops.TILED_MIN_ROWS = min_tiled
 
 
-@pytest.mark.parametrize("m,kind", [(64, "5pt"), (150, "5pt"), (64, "9pt"), (129, "9pt")])
+@pytest.mark.parametrize("m,kind", [(32, "5pt"), (64, "5pt"), (150, "5pt"), (64, "9pt"), (129, "9pt")])
 @pytest.mark.parametrize("seg_lines", [0, 5, 1000, "tile"])
 def test_fused_post_smoothing_with_the_correction_folded_in(m, kind, seg_lines):
     """lmg_stencil_smooth_prolong / lmg_stencil_smooth_tiled_prolong: x_out = J^S(x + P e) in one pass, against the

@@ -161,7 +161,8 @@ class BandedBlockSolver:
     @staticmethod
     def plan(n, w):
         """(k strips, strip size s) minimising the dense bytes per application
-        2*k*s^2 + ((k-1)*w')^2 with equal even strip sizes, or None if banding does not pay."""
+        k s^2 + k s c_w + n_S^2 (strip inverses, the strips' A_II^-1 A_IS on their separator windows of c_w = two
+        separators, Schur-complement inverse) with equal even strip sizes, or None if banding does not pay."""
         best = None
         for k in range(2, 129):
             s = (n - (k - 1) * w) // k
@@ -169,7 +170,7 @@ class BandedBlockSolver:
             if s < 2 * w or s < 32:
                 break
             ns = n - k * s
-            cost = 2 * k * s * s + ns * ns
+            cost = k * s * s + k * s * 2 * (-(-ns // (k - 1))) + ns * ns
             if best is None or cost < best[0]:
                 best = (cost, k, s)
         if best is None or best[0] > 0.5 * n * n:

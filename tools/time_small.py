@@ -53,7 +53,7 @@ for side in (257, 513, 1025):
     print("%d^2: " % side + "   ".join("%s %.2f us" % kv for kv in res))
     # the LDS-tiled fused passes of the same level (what the cycle launches): pre = 3 sweeps from zero + residual,
     # post = 3 sweeps
-    for rows in (16, 24, 32):
+    for rows in (16, 32):
         ops.tune_set("tile_rows", rows)
         pre = chain_us(lambda: ops.stencil_smooth(dA, None, b, 0.8, 3, y, r))
         post = chain_us(lambda: ops.stencil_smooth(dA, x, b, 0.8, 3, y, None))

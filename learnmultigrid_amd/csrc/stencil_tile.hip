@@ -18,7 +18,8 @@
 
 namespace {
 
-constexpr int kRB = 4;                        // consecutive lines of a tile a wave owns: a tile of RR lines is RR / 4 waves
+constexpr int kRB = 2;                        // consecutive lines of a tile a wave owns: a tile of RR lines is RR / 2 waves
+                                              // (4 lines per wave: cfg#2 cycle 0.131 instead of 0.122 ms, cfg#4 equal)
 constexpr int kMaxPat = 64;
 constexpr int kCols = 64;                     // columns of a tile = lanes of a wave
 constexpr int kLS = kCols + 2;                // LDS line stride: one guard column on either side
@@ -347,7 +348,7 @@ int launch5(TArgs a, hipStream_t st)
 static int tile_rows_for(const TArgs &a)
 {
     const int rr = a.lines >= g_tile_big_lines ? g_tile_rows_big : g_tile_rows;
-    return rr == 0 ? 32 : rr;     // measured in the cycle (cfg#4): 0.677 ms with 32-line tiles (8 waves), 0.681 with 16 (4 waves)
+    return rr == 0 ? 32 : rr;     // measured in the cycle (cfg#4): 0.672 ms with 32-line tiles (16 waves), 0.688 with 16 (8 waves)
 }
 
 template <int S, unsigned UM, bool RESID, bool ZERO, bool PROL = false, bool REST = false>

@@ -423,6 +423,8 @@ int lmg_dense_gemv_windows_off(int64_t nblocks, int64_t rows, int64_t cols, cons
  *   lmg_coarse_front: y = blockdiag(M) b[perm[0 .. nblocks*bs)],  tail_out[i] = b[perm[nblocks*bs + i]], i < ntail;
  *   lmg_coarse_back : out[perm[k*rows + r]] (+)= z[k*z_stride + r] + alpha * M_k[r,:] . x[x_offsets[k] ..),
  *                     out[perm[nblocks*rows + i]] (+)= x[i], i < ntail   (accumulate != 0: += , the refinement step).
+ * Every block of d_perm[0 .. nblocks*bs) is a run of consecutive indices (perm[k bs + c] = perm[k bs] + c: a strip of the
+ * banded solver), which lmg_coarse_front relies on.
  * Same sums as lmg_dense_gemv_blockdiag / lmg_dense_gemv_windows_off followed by lmg_gather / lmg_scatter / lmg_axpby. */
 int lmg_coarse_front(int64_t nblocks, int64_t bs, const double *d_M, const double *d_b, const int32_t *d_perm, double *d_y,
                      int64_t ntail, double *d_tail_out, void *stream);

@@ -151,10 +151,25 @@ __global__ void __launch_bounds__(kBlock) dense_gemv_wgrow_kernel(int64_t n, int
         const double2 *M2 = reinterpret_cast<const double2 *>(M + row * m);
         const double2 *x2 = reinterpret_cast<const double2 *>(x);
         double s = 0.0;
-        for (int64_t j = t; j < m / 2; j += kBlock) {
-            const double2 mv = M2[j], xv = x2[j];
-            s += mv.x * xv.x;
-            s += mv.y * xv.y;
+        // all loads of a chunk are issued before its sums (the plain loop waits for every load in turn: a row of a
+        // few thousand entries is 5 steps per lane, i.e. 5 memory latencies); same order of additions
+        constexpr int CH = 8;
+        for (int64_t j0 = t; j0 < m / 2; j0 += (int64_t)CH * kBlock) {
+            double2 mv[CH], xv[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int64_t j = j0 + (int64_t)c * kBlock;
+                const bool in = j < m / 2;
+                mv[c] = M2[in ? j : 0];
+                xv[c] = x2[in ? j : 0];
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (j0 + (int64_t)c * kBlock < m / 2) {
+                    s += mv[c].x * xv[c].x;
+                    s += mv[c].y * xv[c].y;
+                }
+            }
         }
         if ((m & 1) && t == 0) s += M[row * m + m - 1] * x[m - 1];
         s = lmg_wave_sum(s);
@@ -238,12 +253,29 @@ __global__ void __launch_bounds__(kBlock) coarse_front_kernel(int64_t n, int64_t
     const int64_t nwaves = (int64_t)gridDim.x * kBlock / LMG_WAVE;
     for (int64_t row = wave; row < n; row += nwaves) {
         const double2 *M2 = reinterpret_cast<const double2 *>(M + row * bs);
-        const int *p = perm + (row / bs) * bs;
+        // a strip is a run of CONSECUTIVE unknowns (perm[k bs + c] = perm[k bs] + c: the caller's layout), so its
+        // right-hand side is read in place; all loads of a chunk before its sums, same order of additions
+        const double *x = b + perm[(row / bs) * bs];
         double s = 0.0;
-        for (int64_t j = lane; j < bs / 2; j += LMG_WAVE) {
-            const double2 mv = M2[j];
-            s += mv.x * b[p[2 * j]];
-            s += mv.y * b[p[2 * j + 1]];
+        constexpr int CH = 8;
+        for (int64_t j0 = lane; j0 < bs / 2; j0 += (int64_t)CH * LMG_WAVE) {
+            double2 mv[CH];
+            double xa[CH], xb[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int64_t j = j0 + (int64_t)c * LMG_WAVE;
+                const int64_t jj = j < bs / 2 ? j : 0;
+                mv[c] = M2[jj];
+                xa[c] = x[2 * jj];
+                xb[c] = x[2 * jj + 1];
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (j0 + (int64_t)c * LMG_WAVE < bs / 2) {
+                    s += mv[c].x * xa[c];
+                    s += mv[c].y * xb[c];
+                }
+            }
         }
         s = lmg_wave_sum(s);
         if (lane == 0) y[row] = s;
@@ -265,10 +297,25 @@ __global__ void __launch_bounds__(kBlock) coarse_back_kernel(int64_t nb, int64_t
         const double2 *M2 = reinterpret_cast<const double2 *>(M + row * cols);
         const double *x = x0 + xoff[k];
         double s = 0.0;
-        for (int64_t j = lane; j < cols / 2; j += LMG_WAVE) {
-            const double2 mv = M2[j];
-            s += mv.x * x[2 * j];
-            s += mv.y * x[2 * j + 1];
+        constexpr int CH = 4;                     // (all loads of a chunk before its sums, same order of additions)
+        for (int64_t j0 = lane; j0 < cols / 2; j0 += (int64_t)CH * LMG_WAVE) {
+            double2 mv[CH];
+            double xa[CH], xb[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int64_t j = j0 + (int64_t)c * LMG_WAVE;
+                const int64_t jj = j < cols / 2 ? j : 0;
+                mv[c] = M2[jj];
+                xa[c] = x[2 * jj];
+                xb[c] = x[2 * jj + 1];
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (j0 + (int64_t)c * LMG_WAVE < cols / 2) {
+                    s += mv[c].x * xa[c];
+                    s += mv[c].y * xb[c];
+                }
+            }
         }
         s = lmg_wave_sum(s);
         if (lane == 0) {

@@ -72,15 +72,15 @@ struct TArgs {
     int rp_npat;
 };
 
-template <int S, unsigned UM, bool RESID, bool ZERO, int RR, bool PROL = false, bool REST = false>
-__global__ void __launch_bounds__(RR / kRB * LMG_WAVE) stencil_tile_kernel(TArgs a)
+template <int S, unsigned UM, bool RESID, bool ZERO, int RR, bool PROL = false, bool REST = false, int RBV = kRB>
+__global__ void __launch_bounds__(RR / RBV * LMG_WAVE) stencil_tile_kernel(TArgs a)
 {
     static_assert(!PROL || (!RESID && !ZERO), "the correction is folded into post-smoothing passes only");
     static_assert(!REST || (RESID && !PROL), "the restriction replaces the store of the residual");
     // halo: one more with REST -- the residual has to be exact one line / column beyond the stored part
     constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0) + (REST ? 1 : 0);
-    constexpr int kWaves = RR / kRB, kBlock = kWaves * LMG_WAVE;
-    static_assert(RR > 2 * H + 1 && kCols > 2 * H && RR % kRB == 0, "tile smaller than its halo / lines per wave");
+    constexpr int kWaves = RR / RBV, kBlock = kWaves * LMG_WAVE;
+    static_assert(RR > 2 * H + 1 && kCols > 2 * H && RR % RBV == 0, "tile smaller than its halo / lines per wave");
     // LDS holds the two iterate buffers only: right-hand side and pattern ids of a wave's own lines never change and
     // stay in its registers (32-line tiles: 39 KB instead of 60, i.e. four workgroups per CU instead of two).
     __shared__ double s_x[2][RR * kLS];
@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(RR / kRB * LMG_WAVE) stencil_tile_kernel(TArgs
     const int c0 = tx * (kCols - 2 * H) - H, y0 = ty * (RR - 2 * H) - H;
     const int n = a.n;
     const int64_t W = a.W;
-    constexpr int RB = kRB;                                      // consecutive lines of the tile a wave owns
+    constexpr int RB = RBV;                                      // consecutive lines of the tile a wave owns
     constexpr bool DIAG = (UM & 0x145u) != 0;
     const int rb0 = wave * RB;
 
@@ -329,10 +329,11 @@ __global__ void __launch_bounds__(RR / kRB * LMG_WAVE) stencil_tile_kernel(TArgs
 }
 
 int g_tile_rows = 0;        // 0 = chosen per launch (tuning: 16, 32)
+int g_tile_prol_wide_lines = 768;    // grids of at least this many lines: the pass with the correction on 8-wave workgroups
 int g_tile_rows_big = 0;    // the same for grids of at least g_tile_big_lines lines (tuning one level of a cycle)
 int g_tile_big_lines = 0x7fffffff;
 
-template <int S, unsigned UM, bool RESID, bool ZERO, int RR, bool PROL = false, bool REST = false>
+template <int S, unsigned UM, bool RESID, bool ZERO, int RR, bool PROL = false, bool REST = false, int RBV = kRB>
 int launch5(TArgs a, hipStream_t st)
 {
     constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0) + (REST ? 1 : 0);
@@ -340,7 +341,8 @@ int launch5(TArgs a, hipStream_t st)
     a.tiles_y = (a.lines + (RR - 2 * H) - 1) / (RR - 2 * H);
     const int64_t grid = (int64_t)a.tiles_x * a.tiles_y;
     if (grid > 0x7fffffff) return LMG_ERR_CAPACITY;
-    hipLaunchKernelGGL((stencil_tile_kernel<S, UM, RESID, ZERO, RR, PROL, REST>), dim3((unsigned)grid), dim3(RR / kRB * LMG_WAVE), 0, st, a);
+    hipLaunchKernelGGL((stencil_tile_kernel<S, UM, RESID, ZERO, RR, PROL, REST, RBV>), dim3((unsigned)grid), dim3(RR / RBV * LMG_WAVE), 0, st,
+                       a);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }
@@ -355,6 +357,9 @@ template <int S, unsigned UM, bool RESID, bool ZERO, bool PROL = false, bool RES
 int launch4(TArgs a, hipStream_t st)
 {
     if (tile_rows_for(a) == 16) return launch5<S, UM, RESID, ZERO, 16, PROL, REST>(a, st);
+    // the pass with the correction needs 81 VGPRs: a 16-wave workgroup then fills a CU alone; on levels with many tiles
+    // it runs 8 waves of four lines each (2049^2, 9-point: 69 instead of 81 us)
+    if (PROL && a.lines >= g_tile_prol_wide_lines) return launch5<S, UM, RESID, ZERO, 32, PROL, REST, 4>(a, st);
     return launch5<S, UM, RESID, ZERO, 32, PROL, REST>(a, st);
 }
 
@@ -404,6 +409,11 @@ int lmg_tile_tune_set(const char *key, int v)
         (key[9] ? g_tile_rows_big : g_tile_rows) = v;
         return LMG_OK;
     }
+    if (strcmp(key, "tile_prol_wide_lines") == 0) {
+        if (v < 0) return LMG_ERR_ARG;
+        g_tile_prol_wide_lines = v;
+        return LMG_OK;
+    }
     if (strcmp(key, "tile_big_lines") == 0) {
         if (v < 0) return LMG_ERR_ARG;
         g_tile_big_lines = v;
@@ -416,6 +426,7 @@ int lmg_tile_tune_get(const char *key)
     if (strcmp(key, "tile_rows") == 0) return g_tile_rows;
     if (strcmp(key, "tile_rows_big") == 0) return g_tile_rows_big;
     if (strcmp(key, "tile_big_lines") == 0) return g_tile_big_lines;
+    if (strcmp(key, "tile_prol_wide_lines") == 0) return g_tile_prol_wide_lines;
     return LMG_ERR_ARG;
 }
 

@@ -73,7 +73,8 @@ struct TArgs {
 };
 
 template <int S, unsigned UM, bool RESID, bool ZERO, int RR, bool PROL = false, bool REST = false, int RBV = kRB>
-__global__ void __launch_bounds__(RR / RBV * LMG_WAVE) stencil_tile_kernel(TArgs a)
+// (16-wave workgroups: at most 64 VGPRs, so that two of them share a CU -- the variants with the restriction had 65 - 67)
+__global__ void __launch_bounds__(RR / RBV * LMG_WAVE, (RR / RBV == 16 && !PROL) ? 8 : 1) stencil_tile_kernel(TArgs a)
 {
     static_assert(!PROL || (!RESID && !ZERO), "the correction is folded into post-smoothing passes only");
     static_assert(!REST || (RESID && !PROL), "the restriction replaces the store of the residual");
@@ -359,7 +360,9 @@ int launch4(TArgs a, hipStream_t st)
     if (tile_rows_for(a) == 16) return launch5<S, UM, RESID, ZERO, 16, PROL, REST>(a, st);
     // the pass with the correction needs 81 VGPRs: a 16-wave workgroup then fills a CU alone; on levels with many tiles
     // it runs 8 waves of four lines each (2049^2, 9-point: 69 instead of 81 us)
-    if (PROL && a.lines >= g_tile_prol_wide_lines) return launch5<S, UM, RESID, ZERO, 32, PROL, REST, 4>(a, st);
+    if constexpr (PROL) {
+        if (a.lines >= g_tile_prol_wide_lines) return launch5<S, UM, RESID, ZERO, 32, PROL, REST, 4>(a, st);
+    }
     return launch5<S, UM, RESID, ZERO, 32, PROL, REST>(a, st);
 }
 

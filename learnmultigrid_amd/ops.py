@@ -839,10 +839,10 @@ def stencil_smooth_prolong_available(A, P):
 
 
 _FUSED_RESTRICT_ENABLED = True
-# The tiled pass folds the restriction in only on levels of <= 2 M rows: it costs one more halo line / column per tile
-# (30 % more arithmetic at 16-line tiles), which a level of 4 M rows no longer gets back from the saved launch
-# (cfg#4 cycle 0.715 vs 0.720 ms without, 0.731 with it on every level; cfg#2 0.151 vs 0.157 ms).
-TILED_RESTRICT_MAX_ROWS = 2_000_000
+# The tiled pass may fold the restriction in up to this many rows: it costs one more halo line / column per tile.  With
+# 16-line tiles that was a loss from 4 M rows on (30 % more arithmetic); with 32-line tiles it pays on every tiled level
+# (cfg#4 cycle 0.652 vs 0.654 ms with the 2049^2 level excluded, 0.661 without any; cfg#2 0.151 vs 0.157 ms).
+TILED_RESTRICT_MAX_ROWS = 1 << 62
 
 
 def set_fused_restrict_enabled(flag):

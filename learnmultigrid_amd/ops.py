@@ -711,8 +711,9 @@ FUSED_MAX_SWEEPS = 3
 # workgroup per 64 x 16 tile, four waves per sweep).  Measured (tools/time_mid.py, 3 sweeps + residual / 3 sweeps,
 # us): 9-point 2049^2 tile 71 / 54, register 97 / 61, separate 87 / 67; 5-point 2049^2 64 / 50, 67 / 44, 79 / 60;
 # 5-point 1449^2 37 / 28, 59 / 37, 46 / 35; 4097^2: register 166 / 125, separate 300 / 226.  In the cfg#4 cycle
-# the 2049^2 level on the tiled pass: 0.788 -> 0.766 ms.
-FUSED_MIN_ROWS = 8_000_000
+# the 2049^2 level on the tiled pass: 0.788 -> 0.766 ms.  The crossover lies between 9.4 M rows (5-point 3073^2: cycle 0.448 ms tiled,
+# 0.459 register) and 16.8 M (5-point 4097^2: 0.65 vs 0.77; 9-point: 1.905 vs 1.913 at 8193^2 / 7 levels, i.e. equal).
+FUSED_MIN_ROWS = 12_000_000
 # The tiled pass takes over below, down to levels that are a handful of workgroups either way.
 TILED_MIN_ROWS = 4096
 _TILED_ENABLED = True
@@ -814,7 +815,7 @@ def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None, prolong=None, r
 # HBM traffic (the residual / the corrected iterate are never written and re-read); on a cache-resident level the
 # passes are bound by their arithmetic and the extra work costs more than the two small launches it replaces
 # (measured in the cycle, cfg#4: 4097^2 5-point -52 us and -7 us, 2049^2 9-point +8 us and +4 us).
-FUSED_TRANSFER_MIN_ROWS = 8_000_000
+FUSED_TRANSFER_MIN_ROWS = 12_000_000
 _FUSED_PROLONG_ENABLED = True
 
 

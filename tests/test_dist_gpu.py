@@ -63,7 +63,7 @@ def _gpu_worker(rank, world, port, out_dir, transfer="geometric", fuse_all=False
     from conftest import ROOT
     sys.path.insert(0, ROOT)
     if fuse_all:
-        # the product runs the register-blocked passes only from 8 M rows on (LDS-tiled ones below); force them on these small blocks
+        # the product runs the register-blocked passes only from 12 M rows on (LDS-tiled ones below); force them on these small blocks
         from learnmultigrid_amd import ops as _ops
         _ops.FUSED_MIN_ROWS = 0
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)

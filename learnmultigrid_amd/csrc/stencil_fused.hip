@@ -41,6 +41,11 @@ struct MArgs {
     int npat;
     unsigned umask;
     int strips, segs, seg_lines;
+    int items;                // waves of the launch
+    int nb_strips;            // boundary strips (first, last) cut into their own, shorter segments and numbered first: 0, 1 or 2
+    int segs_b, seg_lines_b;
+    int edge_lines;           // length of the first / last segment of the other strips (0: uniform segments)
+    int allow_fast;
     const unsigned char *pid;
     const double *st_val;
     const int *st_mask;
@@ -74,10 +79,11 @@ struct MArgs {
 
 // strip geometry: columns left of the stored part / stored columns of a 128-column window
 template <int H, bool PROL, bool REST> struct StripGeom {
-    // PROL and REST: the window starts on an even column (lane l then owns coarse column c0 / 2 + l).
+    // The window starts on an even column and stores an even number of columns: a lane's pair is stored whole or not
+    // at all (except for the last column of an odd line stride), and with PROL / REST lane l owns coarse column c0 / 2 + l.
     // PROL: its last pair is never exact (lane 63 has no right-hand coarse neighbour): right margin H + 2 or more.
     // REST: the residual must be exact one line / column beyond the stored part: margins H + 1 or more.
-    static constexpr bool EVEN = PROL || REST;
+    static constexpr bool EVEN = true;
     static constexpr int MLmin = REST ? H + 1 : H, MRmin = REST ? H + 1 : (PROL ? H + 2 : H);
     static constexpr int ML = EVEN ? ((MLmin + 1) & ~1) : MLmin;
     static constexpr int U = EVEN ? ((kStripCols - ML - MRmin) & ~1) : kStripCols - ML - MRmin;
@@ -85,14 +91,15 @@ template <int H, bool PROL, bool REST> struct StripGeom {
 
 __device__ __forceinline__ double dpp_lower(double src)      // lane i <- lane i-1, lane 0 <- 0
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), 0x138, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), 0x138, 0xf, 0xf, false);
+    // (bound_ctrl: a lane without a source reads 0 -- no register has to be cleared for it first)
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double dpp_upper(double src)      // lane i <- lane i+1, lane 63 <- 0
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), 0x130, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), 0x130, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -198,80 +205,101 @@ __device__ __forceinline__ void apply_rows_hot(const double (&hv)[9], const d2 &
     }
 }
 
-// Probe builds only (tools/probe/fused_trace.hip): cycle counter of one wave at five points of every step.
-#ifdef LMG_FUSED_TRACE
-__device__ unsigned long long g_fused_trace[64 * 8];
-#define LMG_TRACE(slot)                                                                              \
-    do {                                                                                             \
-        if (item == LMG_FUSED_TRACE && lane == 0 && t - y_begin < 63)                                \
-            s_trace[(t - y_begin) * 8 + (slot)] = __builtin_readcyclecounter();                      \
-    } while (0)
-#else
-#define LMG_TRACE(slot)
+#ifdef LMG_FUSED_WAVETIME
+__device__ unsigned long long g_fused_wavetime[2 * LMG_FUSED_WAVETIME];   // probe builds (tools/probe/fused_wavetime.hip): start / end (100 MHz) of every wave
 #endif
 
 constexpr int kUF = 6;          // steps per loop iteration = period of all register rings
 constexpr int kNBR = 6;         // depth of the b / id rings (>= S + 2)
 
+// ---- work decomposition --------------------------------------------------------------------------------------
+// One item = one wave = (strip, segment of lines).  Items do not cost the same per line: a wave whose loads all
+// stay inside the vectors runs the FAST body (no clamping, no per-element validity, addresses = a scalar row base +
+// a per-lane constant) and, on lines where every lane holds the frequent pattern, takes the values from scalar
+// registers; the waves of the first / last strip (boundary rows: per-lane patterns from LDS on every line) and of
+// the first / last segment (clamped loads) need about twice the instructions per line.  Measured with a per-wave
+// clock (tools/probe/fused_wavetime.hip, 4097^2, 3 sweeps + residual): boundary-strip waves took 94 - 164 us where
+// the others took 54 - 111, and the launch waited for them (0.181 ms vs 0.140 with no boundary rows at all).  So
+// those items get SHORTER segments (about `g_fused_slow_pct` per cent of the steps of a normal item) and are
+// numbered first, i.e. start first.
+struct Item {
+    int strip, out_y0, out_y1;
+};
+
+__device__ __forceinline__ Item decode_item(const MArgs &a, int item)
+{
+    Item it;
+    const int nb_items = a.nb_strips * a.segs_b;
+    if (item < nb_items) {
+        const int sb = item / a.segs_b, k = item - sb * a.segs_b;
+        it.strip = sb == 0 ? 0 : a.strips - 1;
+        it.out_y0 = k * a.seg_lines_b;
+        it.out_y1 = min(a.lines, it.out_y0 + a.seg_lines_b);
+        return it;
+    }
+    const int k = item - nb_items, ns = a.strips - a.nb_strips;
+    const int seg = k / ns;
+    it.strip = k - seg * ns + (a.nb_strips > 0 ? 1 : 0);
+    if (a.edge_lines > 0) {
+        if (seg == 0) {
+            it.out_y0 = 0;
+            it.out_y1 = a.edge_lines;
+        } else if (seg == 1) {
+            it.out_y0 = a.lines - a.edge_lines;
+            it.out_y1 = a.lines;
+        } else {
+            it.out_y0 = a.edge_lines + (seg - 2) * a.seg_lines;
+            it.out_y1 = min(a.lines - a.edge_lines, it.out_y0 + a.seg_lines);
+        }
+    } else {
+        it.out_y0 = seg * a.seg_lines;
+        it.out_y1 = min(a.lines, it.out_y0 + a.seg_lines);
+    }
+    return it;
+}
+
+struct Tables {
+    const double *val;          // [npat][9]
+    const int *mask;            // [npat], bit 16: no usable diagonal
+    const double *rdiag;        // [npat]
+    const double *pv;           // PROL: [pp_npat][4]
+    const int *pm;
+    const double *rv;           // REST: [rp_npat][9]
+    const int *rm;
+};
+
+// The march of one wave down its segment.  FAST: every load of the wave (halo lines, prefetched lines and the coarse
+// vectors included) is inside its array and every element is a row of the matrix -- decided once per wave from scalar
+// quantities; the general body keeps the clamped, validity-tracking code for the waves at the first / last lines.
 // UM: the union slot mask of the matrix, compile time (5-point, 9-point, 1-D chain: anything else runs
 // the separate sweeps) -- a run-time mask costs a scalar branch per slot, stage and line.
-template <int S, unsigned UM, bool RESID, bool ZERO, int PF, bool PROL = false, bool REST = false>
-__global__ void __launch_bounds__(kBlock, 3) stencil_fused_kernel(MArgs a)
+template <int S, unsigned UM, bool RESID, bool ZERO, int PF, bool PROL, bool REST, bool FAST>
+__device__ __forceinline__ void fused_march(const MArgs &a, const Tables &T, const int lane, const int strip, const int out_y0,
+                                            const int out_y1)
 {
-    static_assert(!PROL || (!RESID && !ZERO), "the correction is fused into post-smoothing passes only");
-    static_assert(!REST || (RESID && !PROL), "the restriction replaces the store of the residual");
-    static_assert(kUF % 3 == 0 && kUF % kNBR == 0 && kUF % PF == 0 && S + 2 <= kNBR, "ring periods");
     constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);      // halo in lines and columns
-    __shared__ double s_val[kMaxPat * 9];
-    __shared__ int s_mask[kMaxPat];
-    __shared__ double s_rdiag[kMaxPat];
-    __shared__ double s_pv[PROL ? kMaxPat * 4 : 1];
-    __shared__ int s_pm[PROL ? kMaxPat : 1];
-    __shared__ double s_rv[REST ? kMaxPat * 9 : 1];
-    __shared__ int s_rm[REST ? kMaxPat : 1];
-#ifdef LMG_FUSED_TRACE
-    __shared__ unsigned long long s_trace[64 * 8];
-    for (int i = threadIdx.x; i < 64 * 8; i += kBlock) s_trace[i] = 0;
-#endif
-
-    const int t_ = threadIdx.x;
-    for (int i = t_; i < a.npat * 9; i += kBlock) s_val[i] = a.st_val[i];
-    for (int i = t_; i < a.npat; i += kBlock) {
-        const int m = a.st_mask[i];
-        const double dg = (m & 16) ? a.st_val[i * 9 + 4] : 0.0;
-        s_rdiag[i] = dg != 0.0 ? 1.0 / dg : 0.0;
-        s_mask[i] = dg == 0.0 ? (m | (1 << 16)) : m;             // bit 16: no usable diagonal -> copy x
-    }
-    if (PROL) {
-        for (int i = t_; i < a.pp_npat * 4; i += kBlock) s_pv[i] = a.pp_val[i];
-        for (int i = t_; i < a.pp_npat; i += kBlock) s_pm[i] = a.pp_mask[i];
-    }
-    if (REST) {
-        for (int i = t_; i < a.rp_npat * 9; i += kBlock) s_rv[i] = a.rp_val[i];
-        for (int i = t_; i < a.rp_npat; i += kBlock) s_rm[i] = a.rp_mask[i];
-    }
-    __syncthreads();
-
-    const int lane = t_ & (LMG_WAVE - 1);
-    const int item = (int)blockIdx.x * kWavesPerBlock + (t_ >> 6);
-    if (item >= a.strips * a.segs) return;
-    const int seg = item / a.strips, strip = item - seg * a.strips;
+    const double *s_val = T.val;
+    const int *s_mask = T.mask;
+    const double *s_rdiag = T.rdiag;
+    const double *s_pv = T.pv;
+    const int *s_pm = T.pm;
+    const double *s_rv = T.rv;
+    const int *s_rm = T.rm;
     constexpr int U = StripGeom<H, PROL, REST>::U, ML = StripGeom<H, PROL, REST>::ML;   // columns a strip stores / its left margin
     constexpr int HL = H + (REST ? 1 : 0);                       // halo in lines
     const int n = a.n;
     const int64_t W = a.W;
     const int c0 = strip * U - ML;                               // linear-index offset of lane 0's first element
-    const int out_y0 = seg * a.seg_lines, out_y1 = min(a.lines, out_y0 + a.seg_lines);
-    // lines loaded: [y_begin, y_end); PROL and REST start on an even line, so that the parity of a step is a
-    // compile-time property of its place in the unrolled block
-    const int y_begin = out_y0 - HL - ((PROL || REST) ? ((out_y0 - HL) & 1) : 0), y_end = out_y1 + HL;
+    // lines loaded: [y_begin, y_end); the first one is even, so that the parity of a step is a compile-time
+    // property of its place in the unrolled block (PROL, REST)
+    const int y_begin = out_y0 - HL - ((out_y0 - HL) & 1), y_end = out_y1 + HL;
     const int cidx = 2 * lane;                                   // window column of element 0
     // columns this lane may store (element 0 / 1): inside the strip's inner part and inside the line
     const bool colA = cidx >= ML && cidx < ML + U && c0 + cidx < W;
     const bool colB = cidx + 1 >= ML && cidx + 1 < ML + U && c0 + cidx + 1 < W;
     const double omega = a.omega;
     // hot pattern: id on both elements + both marked as rows; -1 (no hot pattern) never matches
-    const int hot2 = a.hot >= 0 ? (a.hot | (a.hot << 8) | (3 << 16)) : -1;
+    const int hot2 = a.hot >= 0 ? (FAST ? (a.hot | (a.hot << 8)) : (a.hot | (a.hot << 8) | (3 << 16))) : -1;
     double hv[9];
 #pragma unroll
     for (int s = 0; s < 9; ++s) hv[s] = a.hot_val[s];
@@ -279,11 +307,53 @@ __global__ void __launch_bounds__(kBlock, 3) stencil_fused_kernel(MArgs a)
     double hp[9];
 #pragma unroll
     for (int s = 0; s < 9; ++s) hp[s] = PROL ? a.hp[s] : 0.0;
-    const int hotq_even = (PROL && a.hotp[0] >= 0) ? (a.hotp[0] | (3 << 16)) : -1;
-    const int hotq_odd = (PROL && a.hotp[1] >= 0) ? (a.hotp[1] | (3 << 16)) : -1;
+    const int okbits = FAST ? 0 : (3 << 16);
+    const int hotq_even = (PROL && a.hotp[0] >= 0) ? (a.hotp[0] | okbits) : -1;
+    const int hotq_odd = (PROL && a.hotp[1] >= 0) ? (a.hotp[1] | okbits) : -1;
     double e_prev = 0.0;                                          // PROL: the coarse line the previous (even) line brought
 
+    // FAST: byte offsets of the lane inside a line's window; lanes that never store point out of range
+    const unsigned lane16 = (unsigned)lane * 16u, lane8 = (unsigned)lane * 8u, lane2 = (unsigned)lane * 2u;
+    const unsigned st_off_ab = (colA && colB) ? lane16 : kOOB;    // both elements: one 16-byte store
+    const unsigned st_off_a = (colA && !colB) ? lane16 : kOOB;    // element 0 only (the last column of an odd line stride)
+    const unsigned st_off_c = colA ? lane8 : kOOB;                // REST: the coarse row under element 0
+
     auto fetch = [&](int y, Line &L) {
+        if (FAST) {
+            // all of it in range: scalar row base + lane offset, nothing to clamp or to mark
+            const int64_t i0 = (int64_t)y * W + c0;
+            L.ok = 3;
+            unsigned short two;
+            __builtin_memcpy(&two, reinterpret_cast<const char *>(a.pid + i0) + lane2, 2);
+            L.praw = (int)two;
+            const d2u bb = *reinterpret_cast<const d2u *>(reinterpret_cast<const char *>(a.b + i0) + lane16);
+            L.b.x = bb.a;
+            L.b.y = bb.b;
+            if (!ZERO) {
+                const d2u xx = *reinterpret_cast<const d2u *>(reinterpret_cast<const char *>(a.x + i0) + lane16);
+                L.x.x = xx.a;
+                L.x.y = xx.b;
+            } else {
+                L.x.x = L.x.y = 0.0;
+            }
+            if (PROL) {
+                unsigned short twop;
+                __builtin_memcpy(&twop, reinterpret_cast<const char *>(a.ppid + i0) + lane2, 2);
+                L.pp = (int)twop;
+                const int64_t jc0 = (int64_t)((y + 1) >> 1) * a.Wc + (c0 >> 1);
+                L.e = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(a.ec + jc0) + lane8);
+            } else {
+                L.pp = 0;
+                L.e = 0.0;
+            }
+            if (REST) {
+                const int64_t jr0 = (int64_t)((y - S) >> 1) * a.Wc + (c0 >> 1);
+                L.rp = (int)*(reinterpret_cast<const unsigned char *>(a.rpid + jr0) + lane);
+            } else {
+                L.rp = 0;
+            }
+            return;
+        }
         const bool line_ok = y >= 0 && y < a.lines && y < y_end;             // wave-uniform, no branch on it
         const int yc = min(max(y, 0), a.lines - 1);
         const int64_t i = (int64_t)yc * W + c0 + cidx;
@@ -333,15 +403,26 @@ __global__ void __launch_bounds__(kBlock, 3) stencil_fused_kernel(MArgs a)
     double acc_cur = 0.0;                                         // REST: running sum of the coarse row in progress,
     int rp_cur = 0, rp_now = 0;                                   //       its pattern id / the id that came with this line,
     bool st_cur = false, hot_cur = false;                         //       whether this lane stores it / all storing lanes are hot
-    auto store2 = [&](const __amdgpu_buffer_rsrc_t &rs, int y, int p2, double va, double vb) {
+    bool sty_cur = false;                                         //       (FAST) whether its line is one this wave stores
+    auto store2 = [&](const __amdgpu_buffer_rsrc_t &rs, double *base, int y, int p2, double va, double vb) {
         const bool yok = y >= out_y0 && y < out_y1;
-        const int64_t i = (int64_t)y * W + c0 + cidx;
-        const bool stA = yok && colA && ((p2 >> 16) & 1), stB = yok && colB && ((p2 >> 17) & 1);
         u4 v4;
         v4.x = (unsigned)__double2loint(va);
         v4.y = (unsigned)__double2hiint(va);
         v4.z = (unsigned)__double2loint(vb);
         v4.w = (unsigned)__double2hiint(vb);
+        if (FAST) {
+            // a descriptor of the line's window (scalar work); a line that is not stored gets an empty one
+            const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(base + ((int64_t)y * W + c0), 0, yok ? 8 * kStripCols : 0, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(v4, rl, st_off_ab, 0, 0);
+            u2 v2;
+            v2.x = v4.x;
+            v2.y = v4.y;
+            __builtin_amdgcn_raw_buffer_store_b64(v2, rl, st_off_a, 0, 0);
+            return;
+        }
+        const int64_t i = (int64_t)y * W + c0 + cidx;
+        const bool stA = yok && colA && ((p2 >> 16) & 1), stB = yok && colB && ((p2 >> 17) & 1);
         __builtin_amdgcn_raw_buffer_store_b128(v4, rs, (stA && stB) ? (unsigned)i * 8u : kOOB, 0, 0);
         u2 v2;
         v2.x = stA ? v4.x : v4.z;
@@ -371,34 +452,47 @@ __global__ void __launch_bounds__(kBlock, 3) stencil_fused_kernel(MArgs a)
     for (int u = 0; u < PF; ++u) fetch(y_begin + u, pre[u]);
 
     const int t_last = out_y1 - 1 + S + (RESID ? 1 : 0) + (REST ? 1 : 0);   // last step that still produces output
-#ifdef LMG_FUSED_TRACE
-    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ck0 = __builtin_readcyclecounter();
-#endif
     for (int tb = y_begin; tb <= t_last; tb += kUF) {
 #pragma unroll
         for (int u = 0; u < kUF; ++u) {
             const int t = tb + u;
-            LMG_TRACE(0);
             // ---- line t arrives ------------------------------------------------------------------
             const int q0 = u % kNBR;
             {
                 const Line &L = pre[u % PF];
-                const bool okA = L.ok & 1, okB = L.ok & 2, up = L.ok & 4, down = L.ok & 8;
+                const bool okA = FAST || (L.ok & 1), okB = FAST || (L.ok & 2), up = !FAST && (L.ok & 4), down = !FAST && (L.ok & 8);
                 d2 bv, xv;
-                // (selects that only do something in the first / last lines of the matrix)
-                bv.x = okA ? (down ? L.b.y : L.b.x) : 0.0;
-                bv.y = okB ? (up ? L.b.x : L.b.y) : 0.0;
-                xv.x = okA ? (down ? L.x.y : L.x.x) : 0.0;
-                xv.y = okB ? (up ? L.x.x : L.x.y) : 0.0;
-                const int pa = down ? (L.praw >> 8) & 0xff : L.praw & 0xff, pb = up ? L.praw & 0xff : (L.praw >> 8) & 0xff;
+                int pa, pb;
+                if (FAST) {
+                    bv = L.b;
+                    xv = L.x;
+                    pa = L.praw & 0xff;
+                    pb = L.praw >> 8;
+                } else {
+                    // (selects that only do something in the first / last lines of the matrix)
+                    bv.x = okA ? (down ? L.b.y : L.b.x) : 0.0;
+                    bv.y = okB ? (up ? L.b.x : L.b.y) : 0.0;
+                    xv.x = okA ? (down ? L.x.y : L.x.x) : 0.0;
+                    xv.y = okB ? (up ? L.x.x : L.x.y) : 0.0;
+                    pa = down ? (L.praw >> 8) & 0xff : L.praw & 0xff;
+                    pb = up ? L.praw & 0xff : (L.praw >> 8) & 0xff;
+                }
                 if (REST) rp_now = L.rp;
                 if (PROL) {
                     // x + P e_c for the two elements: row (y, x) of P reads e_c at ((y >> 1), (x >> 1)) + {0, 1} x {0, 1};
                     // both elements of a lane share x >> 1 = c0 / 2 + lane.  Same sums in the same order as
                     // lmg_rpat_sweep_grid(SPMV, alpha = 1, beta = 1): acc = 0; acc = acc + v * e per entry; x + acc.
                     const bool odd = (u & 1) != 0;                        // y_begin is even: compile time after unrolling
-                    const int qa = down ? (L.pp >> 8) & 0xff : L.pp & 0xff, qb = up ? L.pp & 0xff : (L.pp >> 8) & 0xff;
-                    const int q2 = (okA ? qa : 0) | ((okB ? qb : 0) << 8) | ((L.ok & 3) << 16);
+                    int qa, qb, q2;
+                    if (FAST) {
+                        qa = L.pp & 0xff;
+                        qb = L.pp >> 8;
+                        q2 = L.pp;
+                    } else {
+                        qa = down ? (L.pp >> 8) & 0xff : L.pp & 0xff;
+                        qb = up ? L.pp & 0xff : (L.pp >> 8) & 0xff;
+                        q2 = (okA ? qa : 0) | ((okB ? qb : 0) << 8) | ((L.ok & 3) << 16);
+                    }
                     const double en = L.e;
                     const double e0 = odd ? e_prev : en, e1 = en;
                     const double e0r = dpp_upper(e0), e1r = dpp_upper(e1);
@@ -429,10 +523,9 @@ __global__ void __launch_bounds__(kBlock, 3) stencil_fused_kernel(MArgs a)
                 }
                 Bq[q0] = bv;
                 X[0][u % 3] = xv;
-                Pq[q0] = (okA ? pa : 0) | ((okB ? pb : 0) << 8) | ((L.ok & 3) << 16);
+                Pq[q0] = FAST ? L.praw : ((okA ? pa : 0) | ((okB ? pb : 0) << 8) | ((L.ok & 3) << 16));
                 Hq[q0] = __all(Pq[q0] == hot2);
             }
-            LMG_TRACE(1);
             fetch(t + PF, pre[u % PF]);
             // ---- stages 1..S: iterate s on line t - s -----------------------------------------------
 #pragma unroll
@@ -467,15 +560,15 @@ __global__ void __launch_bounds__(kBlock, 3) stencil_fused_kernel(MArgs a)
                         nx.x = (mA >> 16) ? xa : xa + omega * (s_rdiag[pA] * rA);
                         nx.y = (mB >> 16) ? xb : xb + omega * (s_rdiag[pB] * rB);
                     }
-                    // elements that are no rows of the matrix stay zero (nothing valid ever reads them)
-                    if (!((p2 >> 16) & 1)) nx.x = 0.0;
-                    if (!((p2 >> 17) & 1)) nx.y = 0.0;
+                    if (!FAST) {
+                        // elements that are no rows of the matrix stay zero (nothing valid ever reads them)
+                        if (!((p2 >> 16) & 1)) nx.x = 0.0;
+                        if (!((p2 >> 17) & 1)) nx.y = 0.0;
+                    }
                 }
                 X[s][xc] = nx;
-                if (s == 1) LMG_TRACE(2);
-                if (s == S) store2(rs_out, t - S, p2, nx.x, nx.y);
+                if (s == S) store2(rs_out, a.out, t - S, p2, nx.x, nx.y);
             }
-            LMG_TRACE(3);
             // ---- residual of the final iterate on line t - S - 1 ---------------------------------------
             if (RESID) {
                 const int y = t - S - 1;
@@ -490,7 +583,7 @@ __global__ void __launch_bounds__(kBlock, 3) stencil_fused_kernel(MArgs a)
                     apply_rows<UM>(s_val, pA, pB, s_mask[pA], s_mask[pB], X[S][xm], X[S][xc], X[S][xp], accA, accB);
                 }
                 if (!REST) {
-                    store2(rs_r, y, p2, Bq[q].x - accA, Bq[q].y - accB);
+                    store2(rs_r, a.r, y, p2, Bq[q].x - accA, Bq[q].y - accB);
                 } else {
                     // b_c = R r without storing r.  Row (Y, X) of R sums its entries in column order: slots 0..2 on line
                     // 2Y - 1, 3..5 on line 2Y, 6..8 on line 2Y + 1 -- so the sum simply continues as the residual lines
@@ -501,6 +594,7 @@ __global__ void __launch_bounds__(kBlock, 3) stencil_fused_kernel(MArgs a)
                     const double wl[3] = {dpp_lower(rB), rA, rB};              // columns 2X - 1, 2X, 2X + 1
                     const bool y_odd = ((u - S - 1) & 1) != 0;                 // y_begin is even: compile time
                     unsigned off_bc = kOOB;
+                    bool emit_line = false;                                    // FAST: the finished row's line is stored by this wave
                     double emit = 0.0;
                     if (!y_odd) {
                         if (hot_cur) {
@@ -528,10 +622,12 @@ __global__ void __launch_bounds__(kBlock, 3) stencil_fused_kernel(MArgs a)
                             }
                         }
                         emit = acc_cur;
-                        if (st_cur) off_bc = (unsigned)(((y - 1) >> 1) * a.Wc + (c0 >> 1) + lane) * 8u;
+                        emit_line = sty_cur;
+                        if (!FAST && st_cur) off_bc = (unsigned)(((y - 1) >> 1) * a.Wc + (c0 >> 1) + lane) * 8u;
                         // ... and start the row below: this wave owns it if it owns its fine node (y + 1, c0 + cidx)
                         rp_cur = rp_now;
-                        st_cur = y + 1 >= out_y0 && y + 1 < out_y1 && colA;
+                        sty_cur = y + 1 >= out_y0 && y + 1 < out_y1;
+                        st_cur = sty_cur && colA;
                         hot_cur = __all(!st_cur || rp_cur == a.hotr);
                         acc_cur = 0.0;
                         if (hot_cur) {
@@ -549,17 +645,82 @@ __global__ void __launch_bounds__(kBlock, 3) stencil_fused_kernel(MArgs a)
                     u2 v2;
                     v2.x = (unsigned)__double2loint(emit);
                     v2.y = (unsigned)__double2hiint(emit);
-                    __builtin_amdgcn_raw_buffer_store_b64(v2, rs_bc, off_bc, 0, 0);
+                    if (FAST) {
+                        // (an even line stores nothing: empty descriptor, like a row of a line another wave owns)
+                        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(
+                            a.bc + ((int64_t)((y - 1) >> 1) * a.Wc + (c0 >> 1)), 0, (y_odd && emit_line) ? 8 * LMG_WAVE : 0, 0x00020000);
+                        __builtin_amdgcn_raw_buffer_store_b64(v2, rl, st_off_c, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b64(v2, rs_bc, off_bc, 0, 0);
+                    }
                 }
             }
-            LMG_TRACE(4);
         }
     }
-#ifdef LMG_FUSED_TRACE
-    if (item == LMG_FUSED_TRACE && lane == 0) {
-        s_trace[63 * 8 + 6] = __builtin_amdgcn_s_memrealtime() - rt0;      // 100 MHz
-        s_trace[63 * 8 + 7] = __builtin_readcyclecounter() - ck0;
-        for (int i = 0; i < 64 * 8; ++i) g_fused_trace[i] = s_trace[i];
+}
+
+template <int S, unsigned UM, bool RESID, bool ZERO, int PF, bool PROL = false, bool REST = false>
+__global__ void __launch_bounds__(kBlock, 3) stencil_fused_kernel(MArgs a)
+{
+    static_assert(!PROL || (!RESID && !ZERO), "the correction is fused into post-smoothing passes only");
+    static_assert(!REST || (RESID && !PROL), "the restriction replaces the store of the residual");
+    static_assert(kUF % 3 == 0 && kUF % kNBR == 0 && kUF % PF == 0 && S + 2 <= kNBR, "ring periods");
+    constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);      // halo in lines and columns
+    __shared__ double s_val[kMaxPat * 9];
+    __shared__ int s_mask[kMaxPat];
+    __shared__ double s_rdiag[kMaxPat];
+    __shared__ double s_pv[PROL ? kMaxPat * 4 : 1];
+    __shared__ int s_pm[PROL ? kMaxPat : 1];
+    __shared__ double s_rv[REST ? kMaxPat * 9 : 1];
+    __shared__ int s_rm[REST ? kMaxPat : 1];
+
+    const int t_ = threadIdx.x;
+    for (int i = t_; i < a.npat * 9; i += kBlock) s_val[i] = a.st_val[i];
+    for (int i = t_; i < a.npat; i += kBlock) {
+        const int m = a.st_mask[i];
+        const double dg = (m & 16) ? a.st_val[i * 9 + 4] : 0.0;
+        s_rdiag[i] = dg != 0.0 ? 1.0 / dg : 0.0;
+        s_mask[i] = dg == 0.0 ? (m | (1 << 16)) : m;             // bit 16: no usable diagonal -> copy x
+    }
+    if (PROL) {
+        for (int i = t_; i < a.pp_npat * 4; i += kBlock) s_pv[i] = a.pp_val[i];
+        for (int i = t_; i < a.pp_npat; i += kBlock) s_pm[i] = a.pp_mask[i];
+    }
+    if (REST) {
+        for (int i = t_; i < a.rp_npat * 9; i += kBlock) s_rv[i] = a.rp_val[i];
+        for (int i = t_; i < a.rp_npat; i += kBlock) s_rm[i] = a.rp_mask[i];
+    }
+    __syncthreads();
+
+    const int lane = t_ & (LMG_WAVE - 1);
+    // the wave index is the same in all lanes: say so, and everything derived from it (strip, segment, lines, row
+    // bases, loop bounds) lives in scalar registers and costs no vector instruction
+    const int item = (int)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(t_ >> 6);
+    if (item >= a.items) return;
+    const Item it = decode_item(a, item);
+    const Tables T = {s_val, s_mask, s_rdiag, s_pv, s_pm, s_rv, s_rm};
+
+    // FAST?  Every line the march touches -- [y_begin, last prefetched line] -- and the coarse lines that travel
+    // with them must lie strictly inside the vectors, for all 128 window columns of the strip.
+    constexpr int U = StripGeom<H, PROL, REST>::U, ML = StripGeom<H, PROL, REST>::ML;
+    constexpr int HL = H + (REST ? 1 : 0);
+    const int c0 = it.strip * U - ML;
+    const int y_begin = it.out_y0 - HL - ((it.out_y0 - HL) & 1);
+    const int t_last = it.out_y1 - 1 + S + (RESID ? 1 : 0) + (REST ? 1 : 0);
+    const int y_fetch = y_begin + ((t_last - y_begin) / kUF + 1) * kUF - 1 + PF;     // last line fetched
+    bool fast = a.allow_fast && y_begin >= (REST ? S + 2 : 1) && y_fetch <= a.lines - 2 &&
+                (int64_t)y_begin * a.W + c0 >= 0 && (int64_t)y_fetch * a.W + c0 + kStripCols < (int64_t)a.n;
+    if (PROL) fast = fast && (int64_t)((y_fetch + 1) >> 1) * a.Wc + (c0 >> 1) + LMG_WAVE <= (int64_t)a.nc;
+    if (REST) fast = fast && (int64_t)((y_fetch - S) >> 1) * a.Wc + (c0 >> 1) + LMG_WAVE <= (int64_t)a.nc;
+#ifdef LMG_FUSED_WAVETIME
+    const unsigned long long wt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (fast) fused_march<S, UM, RESID, ZERO, PF, PROL, REST, true>(a, T, lane, it.strip, it.out_y0, it.out_y1);
+    else fused_march<S, UM, RESID, ZERO, PF, PROL, REST, false>(a, T, lane, it.strip, it.out_y0, it.out_y1);
+#ifdef LMG_FUSED_WAVETIME
+    if (lane == 0 && item < LMG_FUSED_WAVETIME) {
+        g_fused_wavetime[2 * item] = wt0;
+        g_fused_wavetime[2 * item + 1] = (__builtin_amdgcn_s_memrealtime() & ~3ull) | (fast ? 1ull : 0ull) | 2ull;
     }
 #endif
 }
@@ -572,12 +733,16 @@ int g_fused_seg_lines_prol = 0; // segment length of the passes with the correct
 int g_fused_seg_lines_rest = 0;
 int g_fused_want_waves = 5120;  // waves a launch aims at when it cuts the lines into segments ...
 int g_fused_floor_halos = 4;    // ... which are never shorter than this many halos (the redundant lines of a segment: 2 H)
+int g_fused_balance = 1;        // shorter segments for the items that run the slower bodies (boundary strips, first / last segment)
+int g_fused_slow_pct = 55;      // their steps, per cent of a normal item's
+int g_fused_fast = 1;           // 0: every wave runs the general body (tests)
 
 template <int S, unsigned UM, bool RESID, bool ZERO, bool PROL = false, bool REST = false>
 int launch4(MArgs a, hipStream_t st)
 {
     constexpr int H = S + (RESID ? 1 : 0) - (ZERO ? 1 : 0);
     constexpr int U = StripGeom<H, PROL, REST>::U;
+    constexpr int HL = H + (REST ? 1 : 0);
     a.strips = (a.W + U - 1) / U;
     // Segments: about 1.25 x the waves the chip holds at once (256 CUs x 16), never shorter than g_fused_floor_halos
     // halos.  Scanned in the cycle on one box (tools/ab_cycle.py, cfg#4): at 4097^2 the cycle takes 0.885 ms with
@@ -596,9 +761,29 @@ int launch4(MArgs a, hipStream_t st)
         if (seg_lines < floor_lines) seg_lines = floor_lines;
     }
     a.seg_lines = seg_lines;
-    a.segs = (a.lines + seg_lines - 1) / seg_lines;
-    const int items = a.strips * a.segs;
-    const int grid = (items + kWavesPerBlock - 1) / kWavesPerBlock;
+    a.allow_fast = g_fused_fast;
+    a.nb_strips = 0;
+    a.segs_b = 1;
+    a.seg_lines_b = seg_lines;
+    a.edge_lines = 0;
+    if (g_fused_balance) {
+        const int steps = seg_lines + 2 * HL;
+        int slow = (steps * g_fused_slow_pct) / 100 - 2 * HL;
+        if (slow < 2) slow = 2;
+        if (slow < seg_lines) {
+            a.nb_strips = a.strips < 2 ? a.strips : 2;
+            a.seg_lines_b = slow;
+            a.segs_b = (a.lines + slow - 1) / slow;
+            // the first and the last segment of the other strips: long enough for their neighbours' prefetches to stay
+            // inside the grid, i.e. for those to run the FAST body
+            int edge = slow < HL + 2 + kUF + 2 ? HL + 2 + kUF + 2 : slow;
+            if (a.strips > a.nb_strips && a.lines >= 2 * edge + seg_lines) a.edge_lines = edge;
+        }
+    }
+    if (a.edge_lines > 0) a.segs = 2 + (a.lines - 2 * a.edge_lines + seg_lines - 1) / seg_lines;
+    else a.segs = (a.lines + seg_lines - 1) / seg_lines;
+    a.items = a.nb_strips * a.segs_b + (a.strips - a.nb_strips) * a.segs;
+    const int grid = (a.items + kWavesPerBlock - 1) / kWavesPerBlock;
     // (a prefetch distance of 3 lines was measured slower in the cycle -- 0.969 vs 0.933 ms -- and is not compiled)
     hipLaunchKernelGGL((stencil_fused_kernel<S, UM, RESID, ZERO, 2, PROL, REST>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
     LMG_CHECK_LAUNCH();
@@ -681,6 +866,16 @@ int lmg_fused_tune_set(const char *key, int v)
         g_fused_floor_halos = v;
         return LMG_OK;
     }
+    if (strcmp(key, "fused_balance") == 0 || strcmp(key, "fused_fast") == 0) {
+        if (v != 0 && v != 1) return LMG_ERR_ARG;
+        (key[6] == 'b' ? g_fused_balance : g_fused_fast) = v;
+        return LMG_OK;
+    }
+    if (strcmp(key, "fused_slow_pct") == 0) {
+        if (v < 10 || v > 100) return LMG_ERR_ARG;
+        g_fused_slow_pct = v;
+        return LMG_OK;
+    }
     return LMG_ERR_ARG;
 }
 int lmg_fused_tune_get(const char *key)
@@ -693,6 +888,9 @@ int lmg_fused_tune_get(const char *key)
     if (strcmp(key, "fused_seg_lines_rest") == 0) return g_fused_seg_lines_rest;
     if (strcmp(key, "fused_want_waves") == 0) return g_fused_want_waves;
     if (strcmp(key, "fused_floor_halos") == 0) return g_fused_floor_halos;
+    if (strcmp(key, "fused_balance") == 0) return g_fused_balance;
+    if (strcmp(key, "fused_fast") == 0) return g_fused_fast;
+    if (strcmp(key, "fused_slow_pct") == 0) return g_fused_slow_pct;
     return LMG_ERR_ARG;
 }
 
@@ -715,6 +913,8 @@ static int fill_args(MArgs &a, int64_t n, int32_t line_stride, const uint8_t *pi
     a.npat = npat;
     a.umask = union_mask;
     a.strips = a.segs = a.seg_lines = 0;
+    a.items = a.nb_strips = a.edge_lines = a.allow_fast = 0;
+    a.segs_b = a.seg_lines_b = 1;
     a.pid = pid;
     a.st_val = st_val;
     a.st_mask = st_mask;

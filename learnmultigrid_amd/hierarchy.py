@@ -318,6 +318,17 @@ class Hierarchy:
                                self.partials, self.norm2)
         return math.sqrt(self.norm2.item())
 
+    def check_smoothers(self):
+        """Raise if a wavefront Gauss-Seidel band of any level ever gave up waiting for its predecessor
+        (gs_wave.hip then leaves a wrong iterate behind and sets a flag).  One 4-byte D2H read per level that
+        has run the wavefront kernel: call it where the host synchronises anyway (after the residual norm of an
+        outer iteration, after a graph replay)."""
+        chk = getattr(self.ops, "stencil_gs_check", None)
+        if chk is None:
+            return
+        for lev in self.levels[:-1]:
+            chk(lev.A)
+
     def captured_cycle(self, smoother, steps, omega, gs_mode):
         """The same launch sequence as cycle(), captured once into a hipGraph and replayed."""
         key = (smoother, steps, omega, gs_mode)

@@ -18,7 +18,17 @@ F64 = torch.float64
 I32 = torch.int32
 
 
-def _s():
+def _s(*ts):
+    """The HIP stream the launch goes to: the current stream of the device that holds the tensors (the first
+    device tensor among `ts`), or of the current device when none is given."""
+    for t in ts:
+        if t is not None and getattr(t, "is_cuda", False):
+            if t.device.index != torch.cuda.current_device():
+                # a HIP launch goes to the CURRENT device: refuse loudly instead of launching there with another
+                # device's pointers (the solver classes switch devices themselves: solvers.Solver.on_device)
+                raise LmgError("operands live on %s but the current device is cuda:%d: wrap the call in "
+                               "torch.cuda.device(...)" % (t.device, torch.cuda.current_device()))
+            return torch.cuda.current_stream(t.device).cuda_stream
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -143,7 +153,7 @@ class DeviceCSR:
             # 0.3 s to load in a fresh process
             L = _lib.lib()
             counts = torch.zeros(m, dtype=I32, device=dev)
-            check(L.lmg_csr_transpose_count(self.nnz, m, _p(self.colidx), _p(counts), _s()), "lmg_csr_transpose_count")
+            check(L.lmg_csr_transpose_count(self.nnz, m, _p(self.colidx), _p(counts), _s(self.colidx)), "lmg_csr_transpose_count")
             if int(counts.max()) <= int(L.lmg_csr_transpose_max_row()):
                 rp = torch.empty(m + 1, dtype=I32, device=dev)
                 exclusive_scan_i32(counts, rp)
@@ -151,7 +161,7 @@ class DeviceCSR:
                 tc = torch.empty(self.nnz, dtype=I32, device=dev)
                 tv = torch.empty(self.nnz, dtype=F64, device=dev)
                 check(L.lmg_csr_transpose_fill(n, m, _p(self.rowptr), _p(self.colidx), _p(self.vals), _p(rp), _p(counts),
-                                               _p(tc), _p(tv), _s()), "lmg_csr_transpose_fill")
+                                               _p(tc), _p(tv), _s(self.rowptr)), "lmg_csr_transpose_fill")
                 return DeviceCSR(rp, tc, tv, (m, n))
         rows = torch.repeat_interleave(torch.arange(n, device=dev, dtype=I32),
                                        (self.rowptr[1:] - self.rowptr[:-1]).long())
@@ -209,7 +219,7 @@ class PackedCSR:
         table = torch.full((cls._VSET_SLOTS,), -1, dtype=torch.int64, device=dev)
         state = torch.zeros(4, dtype=I32, device=dev)
         check(L.lmg_value_set_insert(vals.numel(), _p(vals), _p(table), cls._VSET_SLOTS, limit,
-                                     _p(state), _s()), "lmg_value_set_insert")
+                                     _p(state), _s(vals)), "lmg_value_set_insert")
         st = state.cpu()
         if int(st[1]):
             return None
@@ -224,7 +234,7 @@ class PackedCSR:
     def _encode_values(vals, uniq, width, out):
         missing = torch.zeros(1, dtype=I32, device=vals.device)
         check(_lib.lib().lmg_value_encode(vals.numel(), _p(vals), _p(uniq), int(uniq.numel()), width, _p(out),
-                                          _p(missing), _s()), "lmg_value_encode")
+                                          _p(missing), _s(vals)), "lmg_value_encode")
         if int(missing):
             raise LmgError("value dictionary does not cover the matrix values")
 
@@ -263,13 +273,13 @@ class PackedCSR:
         self.rowlen = rowlen.to(torch.uint8).contiguous()
         cmin = torch.empty(ntile, dtype=I32, device=dev)
         cmax = torch.empty(ntile, dtype=I32, device=dev)
-        check(L.lmg_pcsr_tile_colrange(n, T, _p(A.rowptr), _p(A.colidx), _p(cmin), _p(cmax), _s()),
+        check(L.lmg_pcsr_tile_colrange(n, T, _p(A.rowptr), _p(A.colidx), _p(cmin), _p(cmax), _s(A.rowptr)),
               "lmg_pcsr_tile_colrange")
         self.tile_colbase = cmin
         if int((cmax - cmin).max()) < 65536:
             self.colmode = 0
             self.col = cls._padded_empty(2 * nnz, dev)
-            check(L.lmg_pcsr_encode_cols16(n, T, _p(A.rowptr), _p(A.colidx), _p(cmin), _p(self.col), _s()),
+            check(L.lmg_pcsr_encode_cols16(n, T, _p(A.rowptr), _p(A.colidx), _p(cmin), _p(self.col), _s(A.rowptr)),
                   "lmg_pcsr_encode_cols16")
         else:
             self.colmode = 1
@@ -337,7 +347,7 @@ class SellCSR:
         slice_len = torch.empty(nsl, dtype=I32, device=dev)
         cmin = torch.empty(nsl, dtype=I32, device=dev)
         cmax = torch.empty(nsl, dtype=I32, device=dev)
-        check(L.lmg_sell_slice_info(n, _p(A.rowptr), _p(A.colidx), _p(slice_len), _p(cmin), _p(cmax), _s()),
+        check(L.lmg_sell_slice_info(n, _p(A.rowptr), _p(A.colidx), _p(slice_len), _p(cmin), _p(cmax), _s(A.rowptr)),
               "lmg_sell_slice_info")
         padded = 64 * int(slice_len.long().sum())
         if padded > cls.MAX_PADDING * nnz or padded >= 2 ** 31 - 64:
@@ -354,7 +364,7 @@ class SellCSR:
         self.col = torch.zeros(padded + 64, dtype=torch.int16 if self.colmode == 0 else I32, device=dev)
         self.val = torch.zeros(padded + 64, dtype=F64, device=dev)
         check(L.lmg_sell_fill(n, _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(self.slice_base), _p(cmin), self.colmode,
-                              _p(self.col), _p(self.val), _s()), "lmg_sell_fill")
+                              _p(self.col), _p(self.val), _s(A.rowptr)), "lmg_sell_fill")
         self.bytes_ = padded * ((2, 4)[self.colmode] + 8) + 16 * nsl + 4 * n
         return self
 
@@ -364,7 +374,7 @@ class SellCSR:
     def update_values(self, A):
         """New values, same pattern (Galerkin rebuild): only the value stream is rewritten."""
         check(_lib.lib().lmg_sell_fill(self.n, _p(A.rowptr), None, _p(A.vals), _p(self.slice_base), _p(self.slice_cmin),
-                                       self.colmode, None, _p(self.val), _s()), "lmg_sell_fill(values)")
+                                       self.colmode, None, _p(self.val), _s(A.rowptr)), "lmg_sell_fill(values)")
         return True
 
 
@@ -372,7 +382,7 @@ def _pid_counts(R):
     """How often every pattern id of a RowPatterns twin occurs (own histogram kernel: a library one costs 0.4 s of
     code-object loading in a fresh process)."""
     cnt = torch.zeros(4 * 256, dtype=I32, device=R.pid.device)
-    check(_lib.lib().lmg_pattern_parity_counts(int(R.n), 1, _p(R.pid), _p(cnt), _s()), "lmg_pattern_parity_counts")
+    check(_lib.lib().lmg_pattern_parity_counts(int(R.n), 1, _p(R.pid), _p(cnt), _s(R.pid)), "lmg_pattern_parity_counts")
     return cnt.cpu().numpy().reshape(4, 256).sum(axis=0)[:R.npat].astype(np.int64)
 
 
@@ -429,7 +439,7 @@ class RowPatterns:
         check(L.lmg_rpat_limits(ctypes.addressof(mp), ctypes.addressof(me)), "lmg_rpat_limits")
         max_pat, max_ent = int(mp.value), int(me.value)
         hashes = torch.empty(n, dtype=torch.int64, device=dev)
-        check(L.lmg_rpat_row_hash_grid(n, gmp, _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(hashes), _s()),
+        check(L.lmg_rpat_row_hash_grid(n, gmp, _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(hashes), _s(A.rowptr)),
               "lmg_rpat_row_hash_grid")
         uniq = PackedCSR._distinct_values(hashes.view(F64), limit=max_pat)
         if uniq is None:
@@ -439,7 +449,7 @@ class RowPatterns:
         PackedCSR._encode_values(hashes.view(F64), uniq, 1, pid)
         del hashes
         rep = torch.full((256,), -1, dtype=I32, device=dev)
-        check(L.lmg_rpat_claim(n, _p(pid), _p(rep), _s()), "lmg_rpat_claim")
+        check(L.lmg_rpat_claim(n, _p(pid), _p(rep), _s(pid)), "lmg_rpat_claim")
         rep = rep[:npat].long()
         if int(rep.min()) < 0:
             return None
@@ -463,7 +473,7 @@ class RowPatterns:
         self.pat_val = A.vals[d_idx].contiguous() if nent else torch.zeros(1, dtype=F64, device=dev)
         mismatch = torch.zeros(1, dtype=I32, device=dev)
         check(L.lmg_rpat_verify_grid(n, A.shape[1], gmp, _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(pid), npat,
-                                     _p(self.pat_ptr), _p(self.pat_off), _p(self.pat_val), _p(mismatch), _s()),
+                                     _p(self.pat_ptr), _p(self.pat_off), _p(self.pat_val), _p(mismatch), _s(A.rowptr)),
               "lmg_rpat_verify_grid")
         if int(mismatch):
             return None                                # a hash collision: not worth a second try
@@ -601,7 +611,7 @@ class ProlongTwin:
         # which patterns occur where: counts by (line parity, column parity)
         n = int(R.n)
         cnt = torch.zeros(4 * 256, dtype=I32, device=dev)
-        check(_lib.lib().lmg_pattern_parity_counts(n, int(W), _p(R.pid), _p(cnt), _s()), "lmg_pattern_parity_counts")
+        check(_lib.lib().lmg_pattern_parity_counts(n, int(W), _p(R.pid), _p(cnt), _s(R.pid)), "lmg_pattern_parity_counts")
         counts = cnt.cpu().numpy().reshape(2, 2, 256)[:, :, :R.npat].astype(np.int64)
         if np.any((counts[0].sum(axis=0) > 0) & ((p_mask & 0xC) != 0)):
             return None                        # a row on an even line reaching the coarse line below: not this shape
@@ -701,7 +711,7 @@ def set_stencil_enabled(flag):
 def _stencil(mode, S, x, b, out, alpha, beta, partials, norm2):
     return _lib.lib().lmg_stencil_sweep(mode, S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask,
                                         _p(x), _p(b), _p(out), float(alpha), float(beta), _p(partials), _p(norm2),
-                                        _s())
+                                        _s(S.pid))
 
 
 FUSED_MAX_SWEEPS = 3
@@ -775,12 +785,12 @@ def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None, prolong=None, r
             check(_lib.lib().lmg_stencil_smooth_tiled_restrict(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask,
                                                                S.hot, hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out),
                                                                T.nc, T.Wc, _p(bc), _p(T.pid), T.npat, _p(T.r_val), _p(T.r_mask),
-                                                               _s()), "lmg_stencil_smooth_tiled_restrict")
+                                                               _s(S.pid)), "lmg_stencil_smooth_tiled_restrict")
             return
         hr = None if T._hot_val is None else ctypes.addressof(T._hot_val)
         check(_lib.lib().lmg_stencil_smooth_restrict(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask, S.hot,
                                                      hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out), T.nc, T.Wc,
-                                                     _p(bc), _p(T.pid), T.npat, _p(T.r_val), _p(T.r_mask), T.hot, hr, _s()),
+                                                     _p(bc), _p(T.pid), T.npat, _p(T.r_val), _p(T.r_mask), T.hot, hr, _s(S.pid)),
               "lmg_stencil_smooth_restrict")
         return
     if prolong is not None:
@@ -793,21 +803,21 @@ def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None, prolong=None, r
             check(_lib.lib().lmg_stencil_smooth_tiled_prolong(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask,
                                                               S.hot, hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out),
                                                               T.nc, T.Wc, _p(e), _p(T.pid), T.npat, _p(T.p_val), _p(T.p_mask),
-                                                              _s()), "lmg_stencil_smooth_tiled_prolong")
+                                                              _s(S.pid)), "lmg_stencil_smooth_tiled_prolong")
             return
         check(_lib.lib().lmg_stencil_smooth_prolong(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask, S.hot,
                                                     hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out), T.nc, T.Wc,
                                                     _p(e), _p(T.pid), T.npat, _p(T.p_val), _p(T.p_mask),
-                                                    ctypes.addressof(T._hot_pairs), ctypes.addressof(T._hot_pval), _s()),
+                                                    ctypes.addressof(T._hot_pairs), ctypes.addressof(T._hot_pval), _s(S.pid)),
               "lmg_stencil_smooth_prolong")
         return
     if _fused_kind(A) == "tile":
         check(_lib.lib().lmg_stencil_smooth_tiled(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask, S.hot,
-                                                  hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out), _p(r_out), _s()),
+                                                  hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out), _p(r_out), _s(S.pid)),
               "lmg_stencil_smooth_tiled")
         return
     check(_lib.lib().lmg_stencil_smooth(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask, S.hot, hv,
-                                        int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out), _p(r_out), _s()),
+                                        int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out), _p(r_out), _s(S.pid)),
           "lmg_stencil_smooth")
 
 
@@ -886,7 +896,7 @@ def set_sell_enabled(flag):
 def _sell(mode, S, x, b, out, alpha, beta, partials, norm2):
     return _lib.lib().lmg_sell_sweep(mode, S.n, _p(S.slice_base), _p(S.slice_len), _p(S.slice_cmin), _p(S.rowlen),
                                      _p(S.col), S.colmode, _p(S.val), S.max_len, _p(x), _p(b), _p(out), float(alpha),
-                                     float(beta), _p(partials), _p(norm2), _s())
+                                     float(beta), _p(partials), _p(norm2), _s(S.slice_base))
 
 
 def set_packed_enabled(flag):
@@ -906,14 +916,14 @@ def _rpat(mode, R, x, b, out, alpha, beta, partials, norm2):
     gmp = None if R._gm is None else ctypes.addressof(R._gm)
     return _lib.lib().lmg_rpat_sweep_grid(mode, R.n, gmp, _p(R.pid), R.npat, R.nent, R.max_len, _p(R.pat_ptr),
                                           _p(R.pat_off), _p(R.pat_val), _p(x), _p(b), _p(out), float(alpha),
-                                          float(beta), _p(partials), _p(norm2), _s())
+                                          float(beta), _p(partials), _p(norm2), _s(R.pid))
 
 
 def _pcsr(mode, P, x, b, out, alpha, beta, partials, norm2):
     rc = _lib.lib().lmg_pcsr_sweep(mode, P.n, P.nnz, P.tile_rows, P.tile_cap, _p(P.tile_base), _p(P.tile_colbase),
                                    _p(P.rowlen), _p(P.col), P.colmode, _p(P.val), P.valmode,
                                    _p(P.dict), P.ndict, _p(x), _p(b), _p(out), float(alpha), float(beta),
-                                   _p(partials), _p(norm2), _s())
+                                   _p(partials), _p(norm2), _s(P.tile_base))
     return rc
 
 
@@ -948,7 +958,7 @@ def csr_residual_norm2(A, x, b, r, partials, norm2):
             check(rc, "lmg_pcsr_sweep(residual)")
             return
     check(_lib.lib().lmg_csr_residual_norm2(A.shape[0], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.vals),
-                                            _p(x), _p(b), _p(r), _p(partials), _p(norm2), _s()),
+                                            _p(x), _p(b), _p(r), _p(partials), _p(norm2), _s(A.rowptr)),
           "lmg_csr_residual_norm2")
 
 
@@ -969,7 +979,7 @@ def csr_jacobi(A, x_in, b, omega, x_out):
             check(rc, "lmg_pcsr_sweep(jacobi)")
             return
     check(_lib.lib().lmg_csr_jacobi(A.shape[0], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.vals),
-                                    _p(x_in), _p(b), float(omega), _p(x_out), _s()), "lmg_csr_jacobi")
+                                    _p(x_in), _p(b), float(omega), _p(x_out), _s(A.rowptr)), "lmg_csr_jacobi")
 
 
 def csr_spmv(A, x, y, alpha=1.0, beta=0.0):
@@ -991,7 +1001,7 @@ def csr_spmv(A, x, y, alpha=1.0, beta=0.0):
             check(rc, "lmg_pcsr_sweep(spmv)")
             return
     check(_lib.lib().lmg_csr_spmv(A.shape[0], A.nnz, _p(A.rowptr), _p(A.colidx), _p(A.vals),
-                                  _p(x), _p(y), float(alpha), float(beta), _s()), "lmg_csr_spmv")
+                                  _p(x), _p(y), float(alpha), float(beta), _s(A.rowptr)), "lmg_csr_spmv")
 
 
 # ---- Gauss-Seidel ---------------------------------------------------------------------
@@ -1036,7 +1046,7 @@ def build_gs_schedule(A_scipy_csr, kind, device):
 def csr_gs_rows(A, x, b, rows):
     _vec_ok(x, b)
     check(_lib.lib().lmg_csr_gs_rows(_p(A.rowptr), _p(A.colidx), _p(A.vals), _p(x), _p(b), _p(rows),
-                                     rows.numel(), _s()), "lmg_csr_gs_rows")
+                                     rows.numel(), _s(A.rowptr)), "lmg_csr_gs_rows")
 
 
 GS_ELL_MAX_SET = 2048            # widest set the one-workgroup ELL executor takes (2 rows per lane);
@@ -1098,7 +1108,7 @@ def stencil_gs(A, x, b, sweeps=1):
         return
     hv = None if S._hot_val is None else ctypes.addressof(S._hot_val)
     check(_lib.lib().lmg_stencil_gs_sweep(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask, S.hot, hv,
-                                          _p(x), _p(b), _p(S._gs_work), int(sweeps), _s()), "lmg_stencil_gs_sweep")
+                                          _p(x), _p(b), _p(S._gs_work), int(sweeps), _s(S.pid)), "lmg_stencil_gs_sweep")
 
 
 def stencil_gs_check(A):
@@ -1121,24 +1131,24 @@ def csr_gs_schedule(A, x, b, sched, sweeps=1):
     if ell is not None and ell[1] is not None:
         _key, K, rows, start, ln, cols, total = ell
         check(_lib.lib().lmg_csr_gs_schedule_ell(x.numel(), _p(A.vals), _p(x), _p(b), _p(rows), _p(start), _p(ln), _p(cols),
-                                                 K, total, _p(sched.d_ptr), sched.nsets, int(sweeps), _s()),
+                                                 K, total, _p(sched.d_ptr), sched.nsets, int(sweeps), _s(A.vals)),
               "lmg_csr_gs_schedule_ell")
         return
     check(_lib.lib().lmg_csr_gs_schedule(_p(A.rowptr), _p(A.colidx), _p(A.vals), _p(x), _p(b),
                                          _p(sched.d_rows), _p(sched.d_ptr), sched.h_ptr.ctypes.data,
-                                         sched.nsets, sched.max_set, int(sweeps), _s()),
+                                         sched.nsets, sched.max_set, int(sweeps), _s(A.rowptr)),
           "lmg_csr_gs_schedule")
 
 
 # ---- vectors ------------------------------------------------------------------------------
 def axpby(alpha, x, beta, y):
     _vec_ok(x, y)
-    check(_lib.lib().lmg_axpby(y.numel(), float(alpha), _p(x), float(beta), _p(y), _s()), "lmg_axpby")
+    check(_lib.lib().lmg_axpby(y.numel(), float(alpha), _p(x), float(beta), _p(y), _s(x)), "lmg_axpby")
 
 
 def vmul(alpha, x, y, out):
     _vec_ok(x, y, out)
-    check(_lib.lib().lmg_vmul(out.numel(), float(alpha), _p(x), _p(y), _p(out), _s()), "lmg_vmul")
+    check(_lib.lib().lmg_vmul(out.numel(), float(alpha), _p(x), _p(y), _p(out), _s(x)), "lmg_vmul")
 
 
 def csr_inverse_diagonal(A):
@@ -1147,43 +1157,43 @@ def csr_inverse_diagonal(A):
     like in the sweep."""
     n = A.shape[0]
     d = torch.empty(n, dtype=F64, device=A.vals.device)
-    check(_lib.lib().lmg_csr_inverse_diagonal(n, _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(d), _s()),
+    check(_lib.lib().lmg_csr_inverse_diagonal(n, _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(d), _s(A.rowptr)),
           "lmg_csr_inverse_diagonal")
     return d
 
 
 def copy(src, dst):
     _vec_ok(src, dst)
-    check(_lib.lib().lmg_copy(dst.numel(), _p(src), _p(dst), _s()), "lmg_copy")
+    check(_lib.lib().lmg_copy(dst.numel(), _p(src), _p(dst), _s(src)), "lmg_copy")
 
 
 def zero(x):
     _vec_ok(x)
-    check(_lib.lib().lmg_zero(x.numel(), _p(x), _s()), "lmg_zero")
+    check(_lib.lib().lmg_zero(x.numel(), _p(x), _s(x)), "lmg_zero")
 
 
 def dot(x, y, partials, out):
     _vec_ok(x, y, partials, out)
-    check(_lib.lib().lmg_dot(x.numel(), _p(x), _p(y), _p(partials), _p(out), _s()), "lmg_dot")
+    check(_lib.lib().lmg_dot(x.numel(), _p(x), _p(y), _p(partials), _p(out), _s(x)), "lmg_dot")
 
 
 def gather(idx, x, buf):
-    check(_lib.lib().lmg_gather(idx.numel(), _p(idx), _p(x), _p(buf), _s()), "lmg_gather")
+    check(_lib.lib().lmg_gather(idx.numel(), _p(idx), _p(x), _p(buf), _s(idx)), "lmg_gather")
 
 
 def scatter(idx, buf, x):
-    check(_lib.lib().lmg_scatter(idx.numel(), _p(idx), _p(buf), _p(x), _s()), "lmg_scatter")
+    check(_lib.lib().lmg_scatter(idx.numel(), _p(idx), _p(buf), _p(x), _s(idx)), "lmg_scatter")
 
 
 def dense_gemv(M, x, y):
     _vec_ok(M, x, y)
-    check(_lib.lib().lmg_dense_gemv(M.shape[0], M.shape[1], _p(M), _p(x), _p(y), _s()), "lmg_dense_gemv")
+    check(_lib.lib().lmg_dense_gemv(M.shape[0], M.shape[1], _p(M), _p(x), _p(y), _s(M)), "lmg_dense_gemv")
 
 
 def dense_gemv_blockdiag(M, x, y):
     """M: (nblocks, bs, bs) contiguous; x, y: nblocks*bs."""
     _vec_ok(M, x, y)
-    check(_lib.lib().lmg_dense_gemv_blockdiag(M.shape[0], M.shape[1], _p(M), _p(x), _p(y), _s()),
+    check(_lib.lib().lmg_dense_gemv_blockdiag(M.shape[0], M.shape[1], _p(M), _p(x), _p(y), _s(M)),
           "lmg_dense_gemv_blockdiag")
 
 
@@ -1196,7 +1206,7 @@ def dense_gemv_windows(M, x, x_stride, y, y_stride, z=None, z_stride=0, alpha=1.
     if x.numel() < need_x or y.numel() < (nb - 1) * y_stride + rows or (z is not None and z.numel() < (nb - 1) * z_stride + rows):
         raise ValueError("dense_gemv_windows: a window leaves its vector")
     check(_lib.lib().lmg_dense_gemv_windows(nb, rows, cols, _p(M), _p(x), int(x_stride), _p(z), int(z_stride), float(alpha),
-                                            _p(y), int(y_stride), _s()), "lmg_dense_gemv_windows")
+                                            _p(y), int(y_stride), _s(M)), "lmg_dense_gemv_windows")
 
 
 def dense_gemv_windows_off(M, x, x_offsets, y, y_stride, z=None, z_stride=0, alpha=1.0):
@@ -1204,13 +1214,13 @@ def dense_gemv_windows_off(M, x, x_offsets, y, y_stride, z=None, z_stride=0, alp
     _vec_ok(M, x, y, z)
     nb, rows, cols = M.shape
     check(_lib.lib().lmg_dense_gemv_windows_off(nb, rows, cols, _p(M), _p(x), _p(x_offsets), _p(z), int(z_stride), float(alpha),
-                                                _p(y), int(y_stride), _s()), "lmg_dense_gemv_windows_off")
+                                                _p(y), int(y_stride), _s(M)), "lmg_dense_gemv_windows_off")
 
 
 def coarse_front(M, b, perm, y, tail_out):
     """y = blockdiag(M) b[perm[:nI]], tail_out = b[perm[nI:]] in one launch (M: (k, s, s), nI = k * s)."""
     _vec_ok(M, b, y, tail_out)
-    check(_lib.lib().lmg_coarse_front(M.shape[0], M.shape[1], _p(M), _p(b), _p(perm), _p(y), tail_out.numel(), _p(tail_out), _s()),
+    check(_lib.lib().lmg_coarse_front(M.shape[0], M.shape[1], _p(M), _p(b), _p(perm), _p(y), tail_out.numel(), _p(tail_out), _s(M)),
           "lmg_coarse_front")
 
 
@@ -1219,11 +1229,11 @@ def coarse_back(W, x_tail, x_offsets, z, alpha, perm, out, accumulate, ntail):
     _vec_ok(W, x_tail, z, out)
     nb, rows, cols = W.shape
     check(_lib.lib().lmg_coarse_back(nb, rows, cols, _p(W), _p(x_tail), _p(x_offsets), _p(z), rows, float(alpha), _p(perm),
-                                     _p(out), 1 if accumulate else 0, int(ntail), _s()), "lmg_coarse_back")
+                                     _p(out), 1 if accumulate else 0, int(ntail), _s(W)), "lmg_coarse_back")
 
 
 def csr_to_dense(A, dense):
-    check(_lib.lib().lmg_csr_to_dense(A.shape[0], A.shape[1], _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(dense), _s()),
+    check(_lib.lib().lmg_csr_to_dense(A.shape[0], A.shape[1], _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(dense), _s(A.rowptr)),
           "lmg_csr_to_dense")
 
 
@@ -1237,7 +1247,7 @@ def batched_inverse(A):
     nmat, n, _ = A.shape
     out = torch.empty_like(A)
     info = torch.zeros(max(nmat, 1), dtype=I32, device=A.device)
-    check(_lib.lib().lmg_batched_inverse(nmat, n, _p(A), _p(out), _p(info), _s()), "lmg_batched_inverse")
+    check(_lib.lib().lmg_batched_inverse(nmat, n, _p(A), _p(out), _p(info), _s(A)), "lmg_batched_inverse")
     return None if bool(info.any()) else out
 
 
@@ -1245,7 +1255,7 @@ def block_copy(nblocks, bs, src, src_stride, dst, dst_stride):
     _vec_ok(src, dst)
     if src.numel() < (nblocks - 1) * src_stride + bs or dst.numel() < (nblocks - 1) * dst_stride + bs:
         raise ValueError("block_copy: a block leaves its vector")
-    check(_lib.lib().lmg_block_copy(int(nblocks), int(bs), _p(src), int(src_stride), _p(dst), int(dst_stride), _s()),
+    check(_lib.lib().lmg_block_copy(int(nblocks), int(bs), _p(src), int(src_stride), _p(dst), int(dst_stride), _s(src)),
           "lmg_block_copy")
 
 
@@ -1253,7 +1263,7 @@ def block_copy(nblocks, bs, src, src_stride, dst, dst_stride):
 def exclusive_scan_i32(inp, out):
     n = inp.numel()
     sc = torch.empty(int(_lib.lib().lmg_scan_scratch_count(n)), dtype=I32, device=inp.device)
-    check(_lib.lib().lmg_exclusive_scan_i32(n, _p(inp), _p(out), _p(sc), _s()), "lmg_exclusive_scan_i32")
+    check(_lib.lib().lmg_exclusive_scan_i32(n, _p(inp), _p(out), _p(sc), _s(inp)), "lmg_exclusive_scan_i32")
 
 
 SPGEMM_MAX_ROW_PRODUCTS = 8192       # LMG_SPGEMM_MAX_ROW_PRODUCTS
@@ -1289,11 +1299,11 @@ class SpGEMMPlan:
         self.row_products = torch.empty(max(n, 1), dtype=I32, device=dev)
         mx = torch.zeros(1, dtype=I32, device=dev)
         check(L.lmg_spgemm_count(n, _p(A.rowptr), _p(A.colidx), _p(B.rowptr), _p(self.row_products),
-                                 _p(mx), _s()), "lmg_spgemm_count")
+                                 _p(mx), _s(A.rowptr)), "lmg_spgemm_count")
         self.max_products = int(mx.item())
         rownnz = torch.zeros(max(n, 1), dtype=I32, device=dev)
         check(L.lmg_spgemm_symbolic(n, _p(A.rowptr), _p(A.colidx), _p(B.rowptr), _p(B.colidx),
-                                    _p(self.row_products), self.max_products, _p(rownnz), _s()),
+                                    _p(self.row_products), self.max_products, _p(rownnz), _s(A.rowptr)),
               "lmg_spgemm_symbolic")
         self.long_rows = None
         if self.max_products > SPGEMM_MAX_ROW_PRODUCTS:
@@ -1312,7 +1322,7 @@ class SpGEMMPlan:
             1 if numeric else 0, self.long_rows.numel(), _p(self.long_rows), _p(A.rowptr), _p(A.colidx),
             _p(A.vals), _p(B.rowptr), _p(B.colidx), _p(B.vals), bc, nsets, _p(val), _p(mark), _p(rownnz),
             _p(out.rowptr) if out is not None else None, _p(out.colidx) if out is not None else None,
-            _p(out.vals) if out is not None else None, _s()), "lmg_spgemm_long_rows")
+            _p(out.vals) if out is not None else None, _s(self.long_rows)), "lmg_spgemm_long_rows")
 
     def _record_buffers(self, dev):
         """Buffers of the product map, or None when recording is off / does not fit."""
@@ -1343,7 +1353,7 @@ class SpGEMMPlan:
                 out.colidx.copy_(c_colidx)
             check(L.lmg_spgemm_numeric_replay(A.shape[0], _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(B.rowptr),
                                               _p(B.vals), _p(self.row_products), self.max_products, _p(out.rowptr),
-                                              _p(out.vals), _p(prod_ptr), _p(dst), _p(segend), _s()),
+                                              _p(out.vals), _p(prod_ptr), _p(dst), _p(segend), _s(A.rowptr)),
                   "lmg_spgemm_numeric_replay")
             if self.long_rows is not None:
                 self._long(True, A, B, None, out)
@@ -1361,13 +1371,13 @@ class SpGEMMPlan:
             check(L.lmg_spgemm_numeric_record(A.shape[0], _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(B.rowptr),
                                               _p(B.colidx), _p(B.vals), _p(self.row_products), self.max_products,
                                               _p(out.rowptr), _p(out.colidx), _p(out.vals), _p(prod_ptr), _p(dst),
-                                              _p(segend), _s()), "lmg_spgemm_numeric_record")
+                                              _p(segend), _s(A.rowptr)), "lmg_spgemm_numeric_record")
             self._rec = (prod_ptr, dst, segend, out.colidx)
         else:
             check(L.lmg_spgemm_numeric(A.shape[0], _p(A.rowptr), _p(A.colidx), _p(A.vals),
                                        _p(B.rowptr), _p(B.colidx), _p(B.vals),
                                        _p(self.row_products), self.max_products,
-                                       _p(out.rowptr), _p(out.colidx), _p(out.vals), _s()),
+                                       _p(out.rowptr), _p(out.colidx), _p(out.vals), _s(A.rowptr)),
                   "lmg_spgemm_numeric")
         if self.long_rows is not None:
             self._long(True, A, B, None, out)
@@ -1545,6 +1555,7 @@ def register_torch_ops():
         A = ent["A"]
         if stencil_gs_available(A):
             stencil_gs(A, x, b, int(sweeps))
+            stencil_gs_check(A)          # one 4-byte read: a timed-out band must not return a wrong iterate silently
             return
         if ent["gs"] is None:
             import scipy.sparse as sp

@@ -40,6 +40,8 @@ class GaussSeidel(IterativeSolver):
             self.iterations += 1
             ops.csr_residual_norm2(A, x, b, r, part, n2)               # GaussSeidel.py:29-30
             self.residual = math.sqrt(n2.item())
+            if wave:
+                ops.stencil_gs_check(A)        # synchronised by the norm read: a timed-out band raises here
             track.append(self.residual)
             if self.residual <= error:
                 self._log("Reached convergence Gauss")
@@ -48,6 +50,8 @@ class GaussSeidel(IterativeSolver):
                 ops.stencil_gs(A, x, b, 1)                             # :37, pipelined wavefront (gs_wave.hip)
             else:
                 ops.csr_gs_schedule(A, x, b, sched, 1)                 # :37
+        if wave:
+            ops.stencil_gs_check(A)
         self.solution = self._column(x)
         self.residual_vector = self._column(r)
         self.track_res = np.array(track, dtype=float).reshape(-1, 1)

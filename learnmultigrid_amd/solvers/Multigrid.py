@@ -132,6 +132,8 @@ class Multigrid(IterativeSolver):
         for _ in range(max_iterations):                                      # :59
             self.iterations += 1
             self.residual = H.residual_norm()                                # :62-63
+            if eff == "GaussSeidel":
+                H.check_smoothers()          # the norm read has synchronised: a timed-out wavefront band raises here
             if self.iterations <= 1:                                         # :64-66
                 self.residual = float(np.linalg.norm(np.ones(shape=(self.dim, 1))))
             track.append(self.residual)
@@ -182,6 +184,8 @@ class Multigrid(IterativeSolver):
         with torch.cuda.stream(H.stream):
             H.cycle(eff, smooth_steps, omega, gs_mode, after_presmooth=hook)
             out = fine.x.cpu().numpy().reshape(n, 1).copy()
+            if eff == "GaussSeidel":
+                H.check_smoothers()
         torch.cuda.current_stream(self._device).wait_stream(H.stream)
         return out
 

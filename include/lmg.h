@@ -432,6 +432,20 @@ int lmg_coarse_back(int64_t nblocks, int64_t rows, int64_t cols, const double *d
                     const int32_t *d_x_offsets, const double *d_z, int64_t z_stride, double alpha, const int32_t *d_perm,
                     double *d_out, int accumulate, int64_t ntail, void *stream);
 
+/* The same two products for blocks that are not runs of consecutive unknowns (coarse.py GridBlockSolver: rectangular
+ * blocks of a grid cut by separator lines AND columns, padded to one size) -- every operand index comes from a table:
+ *   lmg_coarse_front_gather: y[k*bs + r] = sum_c M_k[r][c] * b[d_idx[k*bs + c]]  (d_idx < 0: padding, contributes 0),
+ *                            tail_out[i] = b[d_tail_idx[i]], i < ntail;
+ *   lmg_coarse_back_gather : out[d_oidx[k*rows + r]] (+)= z[k*z_stride + r] + alpha * sum_c M_k[r][c] * x[d_xidx[k*cols + c]]
+ *                            (d_oidx < 0: padding row, skipped),  out[d_tail_idx[i]] (+)= x[i], i < ntail.
+ * bs and cols even, index tables 8-byte aligned.  Replaces the per-cycle SuperLU `spsolve` of Multigrid.py:106 together
+ * with lmg_csr_spmv and lmg_dense_gemv (four launches per application). */
+int lmg_coarse_front_gather(int64_t nblocks, int64_t bs, const double *d_M, const double *d_b, const int32_t *d_idx,
+                            double *d_y, int64_t ntail, const int32_t *d_tail_idx, double *d_tail_out, void *stream);
+int lmg_coarse_back_gather(int64_t nblocks, int64_t rows, int64_t cols, const double *d_M, const double *d_x,
+                           const int32_t *d_xidx, const double *d_z, int64_t z_stride, double alpha, const int32_t *d_oidx,
+                           double *d_out, int accumulate, int64_t ntail, const int32_t *d_tail_idx, void *stream);
+
 /* Setup helper: d_counts[((y & 1) * 2 + (x & 1)) * 256 + id] += number of rows i = y * line_stride + x with pattern id
  * d_pid[i] = id (d_counts: 1024 int32, zeroed by the caller). */
 int lmg_pattern_parity_counts(int64_t n, int32_t line_stride, const uint8_t *d_pid, int32_t *d_counts, void *stream);

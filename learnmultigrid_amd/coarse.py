@@ -365,6 +365,236 @@ class BandedBlockSolver:
         return 8 * (self.k * self.s * self.s + back + self.nS * self.nS)
 
 
+
+class GridBlockSolver:
+    """One-level nested dissection in TWO directions for operators of a row-major grid (n = lines x W unknowns,
+    every coupling within r lines and r columns: the 9-point Galerkin operators of the geometric transfers, r = 1;
+    the 25-point ones of L2-type / learned transfers, r = 2).  Separator lines AND columns, r unknowns thick, cut
+    the grid into Gy x Gx rectangular blocks that only couple through separators; then exactly the block
+    elimination of BandedBlockSolver,
+
+        y_I = A_II^-1 b_I ;  x_S = S^-1 (b_S - A_SI y_I) ;  x_I = y_I - (A_II^-1 A_IS) x_S,
+
+    with dense block inverses (padded to one size s), dense W_k = A_II^-1 A_IS on the cw separator unknowns block k
+    touches and a dense S^-1.  Cutting in both directions is what makes the factors small: strips of whole grid lines
+    need k s^2 with s ~ 5 W, squares (W / G)^2 -- 129^2 unknowns: 63 MB per application (G = 10: 100 blocks of <= 144,
+    2 241 separator unknowns) against 159 MB for 21 strips.  Four launches per application, the permutation folded
+    into the first and the last one (lmg_coarse_front_gather / lmg_coarse_back_gather)."""
+    kind = "grid-block"
+    supports_accumulate = True
+
+    @staticmethod
+    def detect_grid(n, A_host):
+        """(W, lines, r) when every entry (i, j) of the pattern has |line(i) - line(j)| <= r and |col(i) - col(j)| <= r
+        for a line stride W with n = lines * W and a small r, else None."""
+        coo = A_host.tocoo()
+        if coo.nnz == 0:
+            return None
+        d = coo.col.astype(np.int64) - coo.row.astype(np.int64)
+        w = int(np.abs(d).max())
+        for r in (1, 2, 3):
+            for dd in range(r, -1, -1):
+                if (w - dd) % r:
+                    continue
+                W = (w - dd) // r
+                if W < 8 or n % W or n // W < 8 or r * 8 > W:
+                    continue
+                ri, rj = coo.row // W, coo.col // W
+                ci, cj = coo.row % W, coo.col % W
+                if np.all(np.abs(ri - rj) <= r) and np.all(np.abs(ci - cj) <= r):
+                    return int(W), int(n // W), r
+        return None
+
+    @staticmethod
+    def _cuts(m, G, r):
+        """Block coordinate of each of m lines (-1: separator line) for G blocks separated by G - 1 separators of r lines."""
+        lab = np.full(m, -1, dtype=np.int64)
+        free = m - (G - 1) * r
+        if G < 1 or free < G:
+            return None
+        base, extra = divmod(free, G)
+        pos = 0
+        for g in range(G):
+            sz = base + (1 if g < extra else 0)
+            lab[pos:pos + sz] = g
+            pos += sz + r
+        return lab
+
+    @classmethod
+    def plan(cls, W, lines, r):
+        """(Gy, Gx, dense bytes per application) minimising k s^2 + k s cw + nS^2, or None."""
+        best = None
+        for G in range(2, 65):
+            Gx = G
+            Gy = max(2, int(round(G * lines / W)))
+            lx, ly = cls._cuts(W, Gx, r), cls._cuts(lines, Gy, r)
+            if lx is None or ly is None:
+                break
+            bx, by = -(-(W - (Gx - 1) * r) // Gx), -(-(lines - (Gy - 1) * r) // Gy)
+            if bx < 2 * r or by < 2 * r:
+                break
+            s = bx * by
+            s += s % 2
+            k = Gx * Gy
+            nS = W * lines - int((lx >= 0).sum()) * int((ly >= 0).sum())
+            cw = 2 * r * (bx + by) + 4 * r * r
+            cost = 8 * (k * s * s + k * s * cw + nS * nS)
+            if best is None or cost < best[2]:
+                best = (Gy, Gx, cost)
+        return best
+
+    def __init__(self, A, ops_mod, W, lines, r, Gy, Gx):
+        self.ops = ops_mod
+        self._symbolic(A, W, lines, r, Gy, Gx)
+        self.factor(A)
+
+    def _symbolic(self, A, W, lines, r, Gy, Gx):
+        dev = A.device
+        n = A.shape[0]
+        rp, ci = A.rowptr.cpu().numpy(), A.colidx.cpu().numpy()
+        rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(rp))
+        cols = ci.astype(np.int64)
+        ly, lx = self._cuts(lines, Gy, r), self._cuts(W, Gx, r)
+        if ly is None or lx is None:
+            raise ValueError("grid too small for this many blocks")
+        by, bx = ly[np.arange(n) // W], lx[np.arange(n) % W]
+        interior = (by >= 0) & (bx >= 0)
+        blk = np.where(interior, by * Gx + bx, -1)
+        k = Gy * Gx
+        I = np.flatnonzero(interior)
+        order = I[np.argsort(blk[I], kind="stable")]                 # block-major, natural order inside a block
+        sizes = np.bincount(blk[order], minlength=k)
+        if sizes.min() < 1:
+            raise ValueError("empty block")
+        s = int(sizes.max())
+        s += s % 2
+        start = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+        pos = np.arange(order.size) - start[blk[order]]              # position inside the block
+        slot = np.full(n, -1, dtype=np.int64)                        # padded interior slot of every unknown
+        slot[order] = blk[order] * s + pos
+        S = np.flatnonzero(~interior)
+        nS = S.size
+        sidx = np.full(n, -1, dtype=np.int64)
+        sidx[S] = np.arange(nS)
+        self.n, self.nS, self.k, self.s = n, int(nS), int(k), s
+        self.W_, self.lines, self.r, self.Gy, self.Gx = W, lines, r, Gy, Gx
+        eid = np.arange(cols.size, dtype=np.int64)
+        rI, cI = interior[rows], interior[cols]
+        m = rI & cI
+        if np.any(blk[rows[m]] != blk[cols[m]]):
+            raise ValueError("blocks are coupled: the operator is not a grid operator of this radius")
+        if max(k * s * s, nS * nS, cols.size) >= 2 ** 31:
+            raise ValueError("grid coarse solver: dense factors beyond int32 indexing")
+        t = lambda a, dt=torch.int64: torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
+        t32 = lambda a: t(a, torch.int32)
+        self._src_II = t32(eid[m])
+        self._dst_II = t32(blk[rows[m]] * s * s + (slot[rows[m]] % s) * s + (slot[cols[m]] % s))
+        # padding rows of the blocks are identity rows
+        pad_blk = np.repeat(np.arange(k), s - sizes)
+        pad_pos = np.concatenate([np.arange(sz, s) for sz in sizes]) if (s - sizes).sum() else np.zeros(0, dtype=np.int64)
+        self._pad_dst = t32(pad_blk * s * s + pad_pos * s + pad_pos)
+        # separator unknowns every block touches (through A_IS or A_SI): sorted lists, padded to cwp with nS (a zero slot)
+        mIS, mSI = rI & ~cI, ~rI & cI
+        pair_b = np.concatenate([blk[rows[mIS]], blk[cols[mSI]]])
+        pair_s = np.concatenate([sidx[cols[mIS]], sidx[rows[mSI]]])
+        key = np.unique(pair_b * nS + pair_s)
+        kb, ks = key // nS, key % nS
+        cnt = np.bincount(kb, minlength=k)
+        cw = int(cnt.max()) if key.size else 0
+        if cw == 0:
+            raise ValueError("blocks without separators")
+        cwp = cw + (cw & 1)
+        wstart = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+        wloc = np.arange(key.size) - wstart[kb]
+        widx = np.full((k, cwp), nS, dtype=np.int64)
+        widx[kb, wloc] = ks
+        self.cw, self.cwp = cw, cwp
+        if k * s * cwp >= 2 ** 31:
+            raise ValueError("grid coarse solver: dense factors beyond int32 indexing")
+
+        def loc_of(b_, s_):                                          # position of separator s_ in block b_'s list
+            return wloc[np.searchsorted(key, b_ * nS + s_)]
+        self._src_IS = t32(eid[mIS])
+        self._dst_IS = t32(blk[rows[mIS]] * s * cwp + (slot[rows[mIS]] % s) * cwp + loc_of(blk[rows[mIS]], sidx[cols[mIS]]))
+        self._src_SI = t32(eid[mSI])
+        self._dst_SI = t32(blk[cols[mSI]] * cwp * s + loc_of(blk[cols[mSI]], sidx[rows[mSI]]) * s + (slot[cols[mSI]] % s))
+        SI_pat = sp.csr_matrix((eid[mSI] + 1.0, (sidx[rows[mSI]], slot[cols[mSI]])), shape=(nS, k * s))
+        m = ~rI & ~cI
+        self._src_SS = t32(eid[m])
+        self._dst_SS = t32(sidx[rows[m]] * nS + sidx[cols[m]])
+        # where the k local Schur updates (cwp x cwp each) land in S: four passes by the parity of the block
+        # coordinates -- blocks of one parity class share no separator unknown, so a pass writes every entry of S at
+        # most once (fixed order of additions => reproducible bits)
+        valid = widx < nS
+        flat = np.arange(k * cwp * cwp, dtype=np.int64).reshape(k, cwp, cwp)
+        dst = widx[:, :, None] * nS + widx[:, None, :]
+        ok = valid[:, :, None] & valid[:, None, :]
+        color = ((np.arange(k) // Gx) % 2) * 2 + (np.arange(k) % Gx) % 2
+        self._upd = []
+        for c in range(4):
+            sel = ok & (color == c)[:, None, None]
+            if sel.any():
+                d_ = dst[sel]
+                if np.unique(d_).size != d_.size:
+                    raise ValueError("blocks of one parity class share separator unknowns")
+                self._upd.append((t32(flat[sel]), t32(d_)))
+        self._SI_src = t32(np.rint(SI_pat.data).astype(np.int64) - 1)
+        z64 = lambda m_: torch.zeros(m_, dtype=F64, device=dev)
+        self.A_SI = DeviceCSR(t(SI_pat.indptr, torch.int32), t(SI_pat.indices, torch.int32), z64(SI_pat.nnz), (nS, k * s))
+        gI = np.full(k * s, -1, dtype=np.int64)
+        gI[slot[order]] = order
+        self._gI = t32(gI)                                           # padded interior slot -> unknown (-1: padding)
+        self._gS = t32(S)                                            # separator slot -> unknown
+        self._widx = t32(widx.reshape(-1))
+        self.y = z64(k * s)
+        self.bS = z64(nS)
+        self.xS = z64(nS + 2)                                        # (zero slot nS for the padded window entries)
+        self._acc = z64(n)
+        self.blocks = None
+        self.Wm = None
+        self.Sinv = None
+        self._nnz = int(cols.size)
+
+    _place = BandedBlockSolver._place
+
+    def factor(self, A):
+        if A.nnz != self._nnz:
+            raise ValueError("coarse operator changed its sparsity pattern")
+        k, s, cwp, nS = self.k, self.s, self.cwp, self.nS
+        dev = A.vals.device
+        v = A.vals
+        dense = self._place(v, self._src_II, self._dst_II, k * s * s)
+        if self._pad_dst.numel():
+            self.ops.scatter(self._pad_dst, torch.ones(self._pad_dst.numel(), dtype=F64, device=dev), dense)
+        self.blocks = dense_inverse(dense.view(k, s, s))
+        ais = self._place(v, self._src_IS, self._dst_IS, k * s * cwp)
+        asi = self._place(v, self._src_SI, self._dst_SI, k * cwp * s)
+        self.Wm = torch.bmm(self.blocks, ais.view(k, s, cwp)).contiguous()               # k x s x cwp: A_II^-1 A_IS
+        upd = torch.bmm(asi.view(k, cwp, s), self.Wm).reshape(-1)                        # k x cwp x cwp
+        Sc = self._place(v, self._src_SS, self._dst_SS, nS * nS)
+        for sel, dst in self._upd:                       # S[dst] -= upd[sel], every destination once per pass
+            tmp = torch.empty(sel.numel(), dtype=F64, device=dev)
+            cur = torch.empty(sel.numel(), dtype=F64, device=dev)
+            self.ops.gather(sel, upd, tmp)
+            self.ops.gather(dst, Sc, cur)
+            self.ops.axpby(-1.0, tmp, 1.0, cur)
+            self.ops.scatter(dst, cur, Sc)
+        self.Sinv = dense_inverse(Sc.view(nS, nS))
+        self.ops.gather(self._SI_src, v, self.A_SI.vals)
+        self.A_SI.invalidate_packed()
+
+    def apply(self, b, x, accumulate=False):
+        """x = A^-1 b; accumulate: x += A^-1 b."""
+        o = self.ops
+        o.coarse_front_gather(self.blocks, b, self._gI, self.y, self._gS, self.bS)       # y_I = A_II^-1 b_I ; b_S on the side
+        o.csr_spmv(self.A_SI, self.y, self.bS, -1.0, 1.0)                                # g_S = b_S - A_SI y_I
+        o.dense_gemv(self.Sinv, self.bS, self.xS[:self.nS])                              # x_S = S^-1 g_S
+        o.coarse_back_gather(self.Wm, self.xS, self._widx, self.y, -1.0, self._gI, self._gS, x, accumulate)
+
+    def bytes_per_apply(self):
+        return 8 * (self.k * self.s * self.s + self.k * self.s * self.cwp + self.nS * self.nS)
+
+
 class BlockCyclicReduction:
     """Exact block elimination of a banded operator by block cyclic reduction: the unknowns (in their
     natural order, or in reverse Cuthill-McKee order when that is narrower) are cut into m blocks of b >=
@@ -537,14 +767,28 @@ def make_coarse_solver(A, ops_mod, strategy="auto"):
     block cyclic reduction (natural or reverse Cuthill-McKee order, whichever is narrower) beyond that;
     the dense inverse as the last resort (up to MAX_DENSE unknowns)."""
     n = A.shape[0]
-    if strategy not in ("auto", "dense", "banded", "bcr"):
+    if strategy not in ("auto", "dense", "banded", "bcr", "grid"):
         raise ValueError("unknown coarse solver strategy %r" % (strategy,))
     if strategy == "dense" or n < 2048 and strategy == "auto":
         return DenseInverse(A, ops_mod)
     Ah = sp.csr_matrix((A.vals.cpu().numpy(), A.colidx.cpu().numpy(), A.rowptr.cpu().numpy()), shape=A.shape)
     w = max(half_bandwidth(Ah), 1)
+    plan = BandedBlockSolver.plan(n, w) if strategy in ("auto", "banded") else None
+    if strategy in ("auto", "grid") and hasattr(ops_mod, "coarse_front_gather"):
+        # grid operators: blocks cut in both directions (a third of the bytes of whole-line strips)
+        grid = GridBlockSolver.detect_grid(n, Ah)
+        gplan = GridBlockSolver.plan(*grid) if grid is not None else None
+        banded_est = None if plan is None else 8 * (2 * plan[0] * plan[1] ** 2 + (n - plan[0] * plan[1]) ** 2)
+        if gplan is not None and (strategy == "grid" or (gplan[2] <= BANDED_MAX_BYTES and
+                                                         (banded_est is None or gplan[2] < banded_est))):
+            try:
+                return GridBlockSolver(A, ops_mod, grid[0], grid[1], grid[2], gplan[0], gplan[1])
+            except (ValueError, RuntimeError):
+                if strategy == "grid":
+                    raise
+        elif strategy == "grid":
+            raise ValueError("operator is not a grid operator of small radius: cannot use the grid coarse solver")
     if strategy in ("auto", "banded"):
-        plan = BandedBlockSolver.plan(n, w)
         if plan is not None:
             k, s = plan
             est = 8 * (2 * k * s * s + (n - k * s) ** 2)

@@ -752,9 +752,9 @@ int launch4(MArgs a, hipStream_t st)
     if (PROL && g_fused_seg_lines_prol > 0) seg_lines = g_fused_seg_lines_prol;
     if (REST && g_fused_seg_lines_rest > 0) seg_lines = g_fused_seg_lines_rest;
     if (seg_lines <= 0) {
-        // (the pass with the restriction folded in has the longest segments' halo, 2 x 5 lines: one round of waves --
-        // 3 per SIMD -- with 48-line segments measured best in the cycle, 0.701 vs 0.711 ms with 28 lines)
-        const int want = REST ? (g_fused_want_waves * 3) / 5 : g_fused_want_waves;
+        // (round 2 gave the pass with the restriction folded in one round of waves with 48-line segments; with the
+        // balanced decomposition 28 lines measure best for it too: cycle 0.500 vs 0.509 ms)
+        const int want = g_fused_want_waves;
         const int want_segs = (want + a.strips - 1) / a.strips;
         seg_lines = (a.lines + want_segs - 1) / want_segs;
         const int floor_lines = H > 0 ? g_fused_floor_halos * H : 4;

@@ -330,6 +330,99 @@ __global__ void __launch_bounds__(kBlock) coarse_back_kernel(int64_t nb, int64_t
     }
 }
 
+// The same two products for blocks that are NOT runs of consecutive unknowns (coarse.py GridBlockSolver: rectangular
+// blocks of a grid, padded to one size): every operand index comes from a table,
+//   front: y[k*bs + r] = sum_c M_k[r][c] * b[idx[k*bs + c]]  (idx < 0: padding, contributes 0),  tail_out[i] = b[tail_idx[i]]
+//   back : out[oidx[k*rows + r]] (+)= z[k*zs + r] + alpha * sum_c M_k[r][c] * x[xidx[k*cols + c]]  (oidx < 0: padding row),
+//          out[tail_idx[i]] (+)= x[i]
+// One wave per row, all loads of a row issued before its sums (rows are a few hundred entries at most), fixed order.
+__global__ void __launch_bounds__(kBlock) coarse_front_gather_kernel(int64_t n, int64_t bs, const double *M, const double *b,
+                                                                     const int *idx, double *y, int64_t ntail,
+                                                                     const int *tail_idx, double *tail_out)
+{
+    const int lane = threadIdx.x & (LMG_WAVE - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LMG_WAVE;
+    const int64_t nwaves = (int64_t)gridDim.x * kBlock / LMG_WAVE;
+    for (int64_t row = wave; row < n; row += nwaves) {
+        const double2 *M2 = reinterpret_cast<const double2 *>(M + row * bs);
+        const int2 *i2 = reinterpret_cast<const int2 *>(idx + (row / bs) * bs);
+        double s = 0.0;
+        constexpr int CH = 4;
+        for (int64_t j0 = lane; j0 < bs / 2; j0 += (int64_t)CH * LMG_WAVE) {
+            double2 mv[CH];
+            double xa[CH], xb[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int64_t j = j0 + (int64_t)c * LMG_WAVE;
+                const int64_t jj = j < bs / 2 ? j : 0;
+                mv[c] = M2[jj];
+                const int2 g = i2[jj];
+                xa[c] = g.x >= 0 ? b[g.x] : 0.0;
+                xb[c] = g.y >= 0 ? b[g.y] : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (j0 + (int64_t)c * LMG_WAVE < bs / 2) {
+                    s += mv[c].x * xa[c];
+                    s += mv[c].y * xb[c];
+                }
+            }
+        }
+        s = lmg_wave_sum(s);
+        if (lane == 0) y[row] = s;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ntail; i += (int64_t)gridDim.x * kBlock)
+        tail_out[i] = b[tail_idx[i]];
+}
+
+__global__ void __launch_bounds__(kBlock) coarse_back_gather_kernel(int64_t nb, int64_t rows, int64_t cols, const double *M,
+                                                                    const double *x, const int *xidx, const double *z0,
+                                                                    int64_t zs, double alpha, const int *oidx, double *out,
+                                                                    int accumulate, int64_t ntail, const int *tail_idx)
+{
+    const int lane = threadIdx.x & (LMG_WAVE - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LMG_WAVE;
+    const int64_t nwaves = (int64_t)gridDim.x * kBlock / LMG_WAVE;
+    for (int64_t row = wave; row < nb * rows; row += nwaves) {
+        const int64_t k = row / rows, r = row - k * rows;
+        const int d = oidx[row];
+        if (d < 0) continue;                                     // padding row of the block (wave-uniform)
+        const double2 *M2 = reinterpret_cast<const double2 *>(M + row * cols);
+        const int2 *i2 = reinterpret_cast<const int2 *>(xidx + k * cols);
+        double s = 0.0;
+        constexpr int CH = 2;
+        for (int64_t j0 = lane; j0 < cols / 2; j0 += (int64_t)CH * LMG_WAVE) {
+            double2 mv[CH];
+            double xa[CH], xb[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int64_t j = j0 + (int64_t)c * LMG_WAVE;
+                const int64_t jj = j < cols / 2 ? j : 0;
+                mv[c] = M2[jj];
+                const int2 g = i2[jj];
+                xa[c] = x[g.x];
+                xb[c] = x[g.y];
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (j0 + (int64_t)c * LMG_WAVE < cols / 2) {
+                    s += mv[c].x * xa[c];
+                    s += mv[c].y * xb[c];
+                }
+            }
+        }
+        s = lmg_wave_sum(s);
+        if (lane == 0) {
+            const double v = z0[k * zs + r] + alpha * s;
+            out[d] = accumulate ? v + out[d] : v;
+        }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ntail; i += (int64_t)gridDim.x * kBlock) {
+        const int d = tail_idx[i];
+        out[d] = accumulate ? x[i] + out[d] : x[i];
+    }
+}
+
 // How often every pattern id occurs on (even / odd line) x (even / odd column) of a grid with line stride W:
 // counts[((y & 1) * 2 + (x & 1)) * 256 + id] (zeroed by the caller).  Setup helper of ops.ProlongTwin (a library
 // histogram costs 0.4 s of code-object loading in a fresh process).
@@ -734,6 +827,35 @@ int lmg_coarse_back(int64_t nblocks, int64_t rows, int64_t cols, const double *M
     hipLaunchKernelGGL(coarse_back_kernel, dim3(grid_for(nblocks * rows > 0 ? nblocks * rows : 1, kBlock / LMG_WAVE)), dim3(kBlock), 0,
                        lmg_stream(stream), nblocks, rows, cols, M, x, x_offsets, z, z_stride, alpha, perm, out, accumulate,
                        ntail);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_coarse_front_gather(int64_t nblocks, int64_t bs, const double *M, const double *b, const int32_t *idx, double *y,
+                            int64_t ntail, const int32_t *tail_idx, double *tail_out, void *stream)
+{
+    if (nblocks < 0 || bs < 0 || ntail < 0 || (nblocks * bs > 0 && (!M || !b || !idx || !y)) ||
+        (ntail > 0 && (!tail_out || !tail_idx || !b)) || b == y)
+        return LMG_ERR_ARG;
+    if (nblocks * bs == 0 && ntail == 0) return LMG_OK;
+    if (!lmg_aligned16(M) || (bs % 2) || (reinterpret_cast<uintptr_t>(idx) & 7u)) return LMG_ERR_ALIGN;
+    hipLaunchKernelGGL(coarse_front_gather_kernel, dim3(grid_for(nblocks * bs > 0 ? nblocks * bs : 1, kBlock / LMG_WAVE)),
+                       dim3(kBlock), 0, lmg_stream(stream), nblocks * bs, bs, M, b, idx, y, ntail, tail_idx, tail_out);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_coarse_back_gather(int64_t nblocks, int64_t rows, int64_t cols, const double *M, const double *x, const int32_t *xidx,
+                           const double *z, int64_t z_stride, double alpha, const int32_t *oidx, double *out, int accumulate,
+                           int64_t ntail, const int32_t *tail_idx, void *stream)
+{
+    if (nblocks < 0 || rows < 0 || cols < 0 || ntail < 0 || z_stride < 0) return LMG_ERR_ARG;
+    if (nblocks * rows == 0 && ntail == 0) return LMG_OK;
+    if (!M || !x || !xidx || !z || !oidx || !out || (ntail > 0 && !tail_idx) || x == out || z == out) return LMG_ERR_ARG;
+    if (!lmg_aligned16(M) || (cols % 2) || (reinterpret_cast<uintptr_t>(xidx) & 7u)) return LMG_ERR_ALIGN;
+    hipLaunchKernelGGL(coarse_back_gather_kernel, dim3(grid_for(nblocks * rows > 0 ? nblocks * rows : 1, kBlock / LMG_WAVE)),
+                       dim3(kBlock), 0, lmg_stream(stream), nblocks, rows, cols, M, x, xidx, z, z_stride, alpha, oidx, out,
+                       accumulate, ntail, tail_idx);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }

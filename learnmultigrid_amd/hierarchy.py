@@ -59,9 +59,13 @@ class Level:
 class Hierarchy:
     """levels[0] is the fine grid; transfers[l] (n_l x n_{l+1}) prolongates level l+1 -> l."""
 
-    def __init__(self, A, transfers, device, coarse_refine=1, verbose=False, ops_mod=None,
+    def __init__(self, A, transfers, device, coarse_refine="auto", verbose=False, ops_mod=None,
                  use_packed=True, coarse_solver="auto", spgemm_record="lazy", mass=None):
-        """mass: optional fine-level mass matrix; every level then also gets M_(l+1) = Q_l^T M_l Q_l by the
+        """coarse_refine: steps of iterative refinement around every coarsest-level solve; "auto" (default) measures
+        the solver once at setup -- ||b - A x|| / ||b|| of one application -- and refines only when that is not at
+        rounding level (the explicit block inverses of coarse.py reach 1e-14 on the Galerkin operators of grid
+        problems: no refinement, half the launches and bytes of the coarsest solve).
+        mass: optional fine-level mass matrix; every level then also gets M_(l+1) = Q_l^T M_l Q_l by the
         same device SpGEMM (`M_coarse = i.T @ M @ i`, Multigrid.py:273-275, and `mass = Q.T @ mass @ Q` of
         NeuralMG_2D.define_hierarchy, :763): levels[l].M, refreshed by rebuild_mass_numeric()."""
         # `ops_mod` exists for the CPU-only host-logic tests (a test shim stands in for the
@@ -77,7 +81,8 @@ class Hierarchy:
 
     def _build(self, A, transfers, coarse_refine, verbose, use_packed, coarse_solver, spgemm_record, mass):
         ops_ = self.ops
-        self.coarse_refine = int(coarse_refine)
+        self._coarse_refine_arg = coarse_refine
+        self.coarse_refine = 1 if coarse_refine == "auto" else int(coarse_refine)
         self.coarse_strategy = coarse_solver
         self.verbose = verbose
         # every launch of this hierarchy goes to one explicit HIP stream (the legacy default
@@ -144,10 +149,32 @@ class Hierarchy:
         if old is not None and hasattr(old, "factor") and old.n == A.shape[0]:
             try:
                 old.factor(A)                          # same pattern: numeric phase only
+                self._measure_coarse()
                 return
             except ValueError:
                 pass
         self.coarse = make_coarse_solver(A, self.ops, self.coarse_strategy)
+        self._measure_coarse()
+
+    COARSE_AUTO_TOL = 1e-12
+
+    def _measure_coarse(self):
+        """coarse_refine="auto": one application of the fresh factors on a fixed right-hand side; its relative residual
+        decides whether the cycles refine (setup only: one SpMV, one solve, two 8-byte reads)."""
+        if self._coarse_refine_arg != "auto":
+            return
+        lev = self.levels[-1]
+        n = lev.n
+        g = torch.Generator().manual_seed(1234)
+        bh = torch.rand(n, dtype=F64, generator=g) - 0.5
+        nb = float(bh.norm())
+        b = bh.to(self.device)
+        x = torch.zeros(n, dtype=F64, device=self.device)
+        self.coarse.apply(b, x)
+        self.ops.csr_residual_norm2(lev.A, x, b, None, self.partials, self.norm2)       # own kernels only (no library load)
+        rel = math.sqrt(max(float(self.norm2.item()), 0.0)) / nb
+        self.coarse_residual = rel
+        self.coarse_refine = 0 if rel <= self.COARSE_AUTO_TOL else 1
 
     def rebuild_numeric(self, new_vals):
         """Galerkin rebuild after the VALUES of the fine matrix changed (same pattern):

@@ -1232,6 +1232,23 @@ def coarse_back(W, x_tail, x_offsets, z, alpha, perm, out, accumulate, ntail):
                                      _p(out), 1 if accumulate else 0, int(ntail), _s(W)), "lmg_coarse_back")
 
 
+def coarse_front_gather(M, b, idx, y, tail_idx, tail_out):
+    """y[k*s + r] = sum_c M_k[r][c] b[idx[k*s + c]] (idx < 0: 0), tail_out = b[tail_idx] in one launch (M: (k, s, s))."""
+    _vec_ok(M, b, y, tail_out)
+    check(_lib.lib().lmg_coarse_front_gather(M.shape[0], M.shape[1], _p(M), _p(b), _p(idx), _p(y), tail_idx.numel(),
+                                             _p(tail_idx), _p(tail_out), _s(M)), "lmg_coarse_front_gather")
+
+
+def coarse_back_gather(W, x_tail, xidx, z, alpha, oidx, tail_idx, out, accumulate):
+    """out[oidx[k*s + r]] (+)= z[k*s + r] + alpha * sum_c W_k[r][c] x_tail[xidx[k*cw + c]]  (oidx < 0: skipped),
+    out[tail_idx[i]] (+)= x_tail[i] (W: (k, s, cw))."""
+    _vec_ok(W, x_tail, z, out)
+    nb, rows, cols = W.shape
+    check(_lib.lib().lmg_coarse_back_gather(nb, rows, cols, _p(W), _p(x_tail), _p(xidx), _p(z), rows, float(alpha), _p(oidx),
+                                            _p(out), 1 if accumulate else 0, tail_idx.numel(), _p(tail_idx), _s(W)),
+          "lmg_coarse_back_gather")
+
+
 def csr_to_dense(A, dense):
     check(_lib.lib().lmg_csr_to_dense(A.shape[0], A.shape[1], _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(dense), _s(A.rowptr)),
           "lmg_csr_to_dense")

@@ -68,7 +68,7 @@ class Multigrid(IterativeSolver):
         return out
 
     def _setup(self, levels, first_call, coarse_refine):
-        key = (levels, bool(first_call), id(self.matrix), int(coarse_refine),
+        key = (levels, bool(first_call), id(self.matrix), str(coarse_refine),
                None if self.hierarchy is None else tuple(id(h) for h in self.hierarchy))
         if self._hier is None or self._hier_key != key:
             self._hier = Hierarchy(self.matrix, self._transfers(levels, first_call), self._device,
@@ -96,7 +96,7 @@ class Multigrid(IterativeSolver):
     @on_device
     def solve(self, levels=2, smoother="Jacobi", smooth_steps=1, max_iterations=100, error=1e-08,
               initial_guess=None, cycle="V", first_call=False, *, omega=1.0,
-              smoother_semantics="as_shipped", gs_mode="lexicographic", coarse_refine=1,
+              smoother_semantics="as_shipped", gs_mode="lexicographic", coarse_refine="auto",
               use_graph=False, mutate_initial_guess=False):
         if cycle != "V":
             raise ValueError("Cycle type unknown: %r" % (cycle,))            # :55-57
@@ -155,7 +155,7 @@ class Multigrid(IterativeSolver):
     @on_device
     def v_cycle(self, A, u0, rhs, smoother, smooth_steps, error, levels, first_call=False, *,
                 omega=1.0, smoother_semantics="as_shipped", gs_mode="lexicographic",
-                coarse_refine=1):
+                coarse_refine="auto"):
         """One V-cycle on (A, rhs) from u0; returns a fresh (n,1) array.  u0 receives the
         pre-smoothed iterate like in the reference (:88-89)."""
         if levels < 2:

@@ -130,6 +130,27 @@ def dense_gemv_windows_off(M, x, x_offsets, y, y_stride, z=None, z_stride=0, alp
         yn[k * y_stride:k * y_stride + rows] = out[k]
 
 
+def coarse_front_gather(M, b, idx, y, tail_idx, tail_out):
+    k, s, _ = M.shape
+    bn, gi = _np(b), _np(idx)
+    seg = np.where(gi >= 0, bn[np.maximum(gi, 0)], 0.0).reshape(k, s)
+    for i in range(k):
+        _np(y)[i * s:(i + 1) * s] = K.dense_gemv(np.ascontiguousarray(_np(M[i])), np.ascontiguousarray(seg[i]))
+    _np(tail_out)[:] = bn[_np(tail_idx)]
+
+
+def coarse_back_gather(Wm, x_tail, xidx, z, alpha, oidx, tail_idx, out, accumulate):
+    k, s, cwp = Wm.shape
+    xn, wi, zn, gi, on = _np(x_tail), _np(xidx).reshape(k, cwp), _np(z), _np(oidx), _np(out)
+    for i in range(k):
+        v = zn[i * s:(i + 1) * s] + alpha * K.dense_gemv(np.ascontiguousarray(_np(Wm[i])), np.ascontiguousarray(xn[wi[i]]))
+        g = gi[i * s:(i + 1) * s]
+        ok = g >= 0
+        on[g[ok]] = v[ok] + on[g[ok]] if accumulate else v[ok]
+    ti = _np(tail_idx)
+    on[ti] = xn[:ti.size] + on[ti] if accumulate else xn[:ti.size]
+
+
 def block_copy(nblocks, bs, src, src_stride, dst, dst_stride):
     sn, dn = _np(src), _np(dst)
     for k in range(nblocks):

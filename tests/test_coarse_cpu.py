@@ -32,7 +32,8 @@ def test_banded_block_solver_matches_superlu():
     n = Ac.shape[0]
     assert coarse.half_bandwidth(Ac) == 66
     dA = DeviceCSR.from_scipy(Ac, "cpu")
-    solver = coarse.make_coarse_solver(dA, shim, "auto")
+    assert coarse.make_coarse_solver(dA, shim, "auto").kind == "grid-block"       # grid operators: blocks cut both ways
+    solver = coarse.make_coarse_solver(dA, shim, "banded")
     assert solver.kind == "banded-block" and solver.k >= 4
     rng = np.random.default_rng(0)
     b = rng.standard_normal(n)
@@ -154,7 +155,60 @@ def test_block_cyclic_reduction_reorders_scrambled_operators():
 def test_auto_strategy_switches_to_cyclic_reduction_when_banded_factors_get_large(monkeypatch):
     Ac = galerkin_operator(64)
     dA = DeviceCSR.from_scipy(Ac, "cpu")
-    assert coarse.make_coarse_solver(dA, shim, "auto").kind == "banded-block"
+    assert coarse.make_coarse_solver(dA, shim, "auto").kind == "grid-block"
     monkeypatch.setattr(coarse, "BANDED_MAX_BYTES", 1 << 20)
     monkeypatch.setattr(coarse, "DENSE_PREFERRED_BYTES", 1 << 20)
     assert coarse.make_coarse_solver(dA, shim, "auto").kind == "block-cyclic-reduction"
+
+
+def test_grid_block_solver_matches_superlu():
+    """Blocks cut in both grid directions (GridBlockSolver): 9-point Galerkin operator (r = 1), 25-point operator of an
+    L2-type transfer (r = 2), a non-square grid; against SuperLU to rounding, with far fewer dense bytes than whole-line
+    strips; numeric refactorisation on the same pattern; accumulate mode."""
+    cases = [galerkin_operator(64), _l2_galerkin(41)]
+    A, _ = P.poisson_2d_structured(64)
+    Pm = P.tensor_interpolator_2d(65)
+    G = sp.csr_matrix(Pm.T @ A @ Pm)                       # 33 x 33 -> cut a 33 x 24 sub-grid out of it (still a grid operator)
+    keep = np.flatnonzero((np.arange(33 * 33) // 33) < 64)
+    cases.append(sp.csr_matrix(sp.kron(sp.identity(3), G).tocsr()[:33 * 64][:, :33 * 64] + sp.diags(np.ones(33 * 64 - 33), 33) * 0.01
+                               + sp.diags(np.ones(33 * 64 - 33), -33) * 0.01))
+    for Ac in cases:
+        Ac = sp.csr_matrix(Ac)
+        Ac.sort_indices()
+        n = Ac.shape[0]
+        grid = coarse.GridBlockSolver.detect_grid(n, Ac)
+        assert grid is not None, n
+        dA = DeviceCSR.from_scipy(Ac, "cpu")
+        solver = coarse.make_coarse_solver(dA, shim, "grid")
+        assert solver.kind == "grid-block" and solver.k >= 4
+        rng = np.random.default_rng(2)
+        b = rng.standard_normal(n)
+        x = torch.zeros(n, dtype=torch.float64)
+        solver.apply(torch.from_numpy(b.copy()), x)
+        want = spla.spsolve(sp.csc_matrix(Ac), b)
+        err = np.linalg.norm(x.numpy() - want) / np.linalg.norm(want)
+        assert err < 1e-12, (n, err)
+        x2 = x.clone()
+        solver.apply(torch.from_numpy(b.copy()), x2, accumulate=True)
+        assert np.allclose(x2.numpy(), 2 * x.numpy(), rtol=1e-14, atol=0)
+        # new values, same pattern
+        A2 = Ac.copy()
+        A2.data = A2.data * (1.0 + 0.05 * rng.random(A2.nnz))
+        solver.factor(DeviceCSR.from_scipy(A2, "cpu"))
+        solver.apply(torch.from_numpy(b.copy()), x)
+        want2 = spla.spsolve(sp.csc_matrix(A2), b)
+        assert np.linalg.norm(x.numpy() - want2) / np.linalg.norm(want2) < 1e-11
+    # the planner prefers it to whole-line strips on a 129^2 grid and needs well under half their bytes
+    plan = coarse.GridBlockSolver.plan(129, 129, 1)
+    k, s = coarse.BandedBlockSolver.plan(129 * 129, 130)
+    assert plan is not None and plan[2] < 0.5 * 8 * (2 * k * s * s + (129 * 129 - k * s) ** 2)
+
+
+def test_grid_detection_refuses_non_grid_operators():
+    A, _ = P.poisson_2d_structured(48)
+    rng = np.random.default_rng(1)
+    p = rng.permutation(A.shape[0])
+    Ap = sp.csr_matrix(A[p][:, p])
+    assert coarse.GridBlockSolver.detect_grid(Ap.shape[0], Ap) is None
+    A1, _ = P.poisson_1d_fd(4096)
+    assert coarse.GridBlockSolver.detect_grid(A1.shape[0], sp.csr_matrix(A1)) is None

@@ -218,6 +218,26 @@ int lmg_stencil_smooth_tiled_restrict(int64_t n, int32_t line_stride, const uint
                                       int32_t coarse_stride, double *d_b_coarse, const uint8_t *d_r_pid,
                                       int32_t r_npat, const double *d_r_val, const int32_t *d_r_mask, void *stream);
 
+/* ---- fused smoothing passes for grid operators with VARIABLE coefficients (csrc/dia_tile.hip) ------------------------
+ * The operators the reference's learned transfers are built for (variable-coefficient / jittered-mesh stiffness
+ * matrices, Multigrid.py:306-370, :741-765) have the 3x3 slot geometry of lmg_stencil_sweep -- every entry at
+ * column - row = c * line_stride + d, c, d in {-1, 0, 1} -- but no repeating rows.  Their DIA twin stores one fp64 array
+ * of n values per slot of the union mask, slots ascending: d_dia[q * n + row] (40 B/row for a 5-point operator; a row
+ * without that slot holds +0.0, bitwise neutral for finite iterates like an explicit zero of the CSR input).
+ *   lmg_dia_fill   : d_dia from sorted CSR; *d_mismatch |= 1 if an entry is no slot of the mask (d_dia = NULL: probe only,
+ *                    the slots seen are OR-ed into *d_mask_out);
+ *   lmg_dia_smooth : x_out = J^sweeps(x_in) (x_in = NULL: zero iterate), r_out = b - A x_out (optional), sweeps 1..3, in
+ *                    ONE pass: the `sweeps` forward relaxations of pyamg's gauss_seidel call sites in their weighted-
+ *                    Jacobi form (Multigrid.py:88, :121; Jacobi.py:35) plus the residual of :90 -- a workgroup per
+ *                    64-column tile, the matrix values of a lane's rows in registers for all sweeps, the iterate in LDS;
+ *                    same bits as lmg_csr_jacobi x sweeps + lmg_csr_residual_norm2.  Union masks: 5-point, both 7-point
+ *                    orientations, 9-point (lmg_dia_smooth_supported). */
+int lmg_dia_smooth_supported(uint32_t union_mask);
+int lmg_dia_fill(int64_t n, int32_t line_stride, const int32_t *d_rowptr, const int32_t *d_colidx, const double *d_vals,
+                 uint32_t union_mask, double *d_dia, int32_t *d_mismatch, uint32_t *d_mask_out, void *stream);
+int lmg_dia_smooth(int64_t n, int32_t line_stride, uint32_t union_mask, const double *d_dia, int sweeps,
+                   const double *d_x_in, const double *d_b, double omega, double *d_x_out, double *d_r_out, void *stream);
+
 /* The same pass with the coarse-grid correction folded in (Multigrid.py:115 + :121 in one pass):
  *     x_out = J^sweeps(x_in + P e_coarse)
  * for a prolongation P whose row (y, x) -- y = row / line_stride, x = row % line_stride -- reads

@@ -54,6 +54,9 @@ SIGNATURES = {
                                                     _i64, _i32, _p, _p, _i32, _p, _p, _p]),
     "lmg_stencil_smooth_tiled_restrict": (_c.c_int, [_i64, _i32, _p, _i32, _p, _p, _c.c_uint32, _i32, _p, _c.c_int, _p, _p, _f64, _p,
                                                      _i64, _i32, _p, _p, _i32, _p, _p, _p]),
+    "lmg_dia_smooth_supported": (_c.c_int, [_c.c_uint32]),
+    "lmg_dia_fill": (_c.c_int, [_i64, _i32, _p, _p, _p, _c.c_uint32, _p, _p, _p, _p]),
+    "lmg_dia_smooth": (_c.c_int, [_i64, _i32, _c.c_uint32, _p, _c.c_int, _p, _p, _f64, _p, _p, _p]),
     "lmg_stencil_smooth_prolong_supported": (_c.c_int, [_c.c_uint32]),
     "lmg_stencil_smooth_prolong": (_c.c_int, [_i64, _i32, _p, _i32, _p, _p, _c.c_uint32, _i32, _p, _c.c_int, _p, _p, _f64, _p,
                                               _i64, _i32, _p, _p, _i32, _p, _p, _p, _p, _p]),

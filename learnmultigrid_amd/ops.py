@@ -48,7 +48,8 @@ def _vec_ok(*ts):
 class DeviceCSR:
     """CSR matrix resident in HBM: int32 rowptr[n+1], int32 colidx[nnz], fp64 vals[nnz]."""
 
-    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz", "packed", "patterns", "sell", "stencil", "prolong", "restrict")
+    __slots__ = ("rowptr", "colidx", "vals", "shape", "nnz", "packed", "patterns", "sell", "stencil", "prolong", "restrict",
+                 "dia")
 
     def __init__(self, rowptr, colidx, vals, shape):
         if rowptr.dtype != I32 or colidx.dtype != I32 or vals.dtype != F64:
@@ -64,6 +65,7 @@ class DeviceCSR:
         self.stencil = None          # StencilTwin view of `patterns` (3x3 grid stencils), preferred
         self.prolong = None          # ProlongTwin view of `patterns` (2x2-window grid prolongations)
         self.restrict = None         # RestrictTwin view of `patterns` (their transposes)
+        self.dia = None              # DiaTwin (grid operators with per-row values): fused smoothing passes only
 
     def pack(self, patterns=None, line_strides=None):
         """Build (once) the lossless twin the sweep kernels prefer; keeps the CSR arrays.
@@ -91,6 +93,10 @@ class DeviceCSR:
         if self.sell is not None:
             return self.sell
         if self.packed is None:
+            if self.dia is None and _DIA_ENABLED and self.shape[0] == self.shape[1]:
+                # variable-coefficient grid operators: slot arrays for the fused smoothing passes, next to the
+                # packed CSR that serves the single sweeps / SpMV
+                self.dia = DiaTwin.from_csr(self)
             self.packed = PackedCSR.from_csr(self)
             # long rows whose values do not fit a dictionary: the sliced-ELL twin reads them without
             # LDS staging (the packed kernel's row-strided LDS walk is bank-conflict-bound there)
@@ -111,6 +117,7 @@ class DeviceCSR:
         self.stencil = None
         self.prolong = None
         self.restrict = None
+        self.dia = None
 
     def repack_values(self):
         """After the values changed in place: refresh the twins (cheaply if possible)."""
@@ -123,6 +130,8 @@ class DeviceCSR:
                 self.pack()
         if self.sell is not None:
             self.sell.update_values(self)
+        if self.dia is not None and not self.dia.update_values(self):
+            self.dia = None
         if self.packed is not None and not self.packed.update_values(self):
             self.packed = None
             self.pack(patterns=False)
@@ -690,10 +699,83 @@ class RestrictTwin:
         return self
 
 
+class DiaTwin:
+    """Slot arrays of a grid operator with per-row values for lmg_dia_smooth (see include/lmg.h): every entry at
+    column - row = c * W + d, c, d in {-1, 0, 1}, for ONE line stride W; dia[q * n + row] = the entry of `row` in slot
+    number q of the union mask (+0.0 where the row has none).  Built and verified on the device: W is guessed from a
+    few rows in the middle of the matrix, a probe pass collects the slots of ALL entries for that W and refuses the
+    matrix if any entry is not a slot; from_csr returns None for everything that does not fit (the packed-CSR sweeps
+    then run one launch per sweep)."""
+
+    __slots__ = ("n", "W", "umask", "nslots", "dia", "bytes_")
+    MIN_ROWS = 4096
+
+    @staticmethod
+    def _probe(A, W, umask, dia):
+        dev = A.vals.device
+        flags = torch.zeros(2, dtype=I32, device=dev)
+        check(_lib.lib().lmg_dia_fill(A.shape[0], int(W), _p(A.rowptr), _p(A.colidx), _p(A.vals), int(umask), _p(dia),
+                                      flags.data_ptr(), flags.data_ptr() + 4, _s(A.rowptr)), "lmg_dia_fill")
+        f = flags.cpu().numpy()
+        return int(f[0]), int(f[1]) & 0x1FF
+
+    @classmethod
+    def from_csr(cls, A):
+        n = A.shape[0]
+        if n < cls.MIN_ROWS or A.nnz == 0 or A.nnz > 9 * n or not A.vals.is_cuda or n >= 2 ** 31 - 4096:
+            return None
+        # candidate strides from the longest of a few rows in the middle: its largest |column - row| is W - 1, W or W + 1
+        mid = n // 2
+        rp = A.rowptr[mid:mid + 9].cpu().numpy().astype(np.int64)
+        ci = A.colidx[rp[0]:rp[-1]].cpu().numpy().astype(np.int64)
+        rows = np.repeat(np.arange(mid, mid + 8), np.diff(rp))
+        off = np.abs(ci - rows)
+        mx = int(off.max()) if off.size else 0
+        if mx < 4:
+            return None
+        # (several strides can fit -- a 7-point operator also reads as the other 7-point orientation of stride W + 1;
+        # everything is a linear index, so any of them is correct: prefer the one that cuts the rows into whole lines)
+        for W in sorted((mx, mx - 1, mx + 1), key=lambda w: (n % w != 0 if w > 0 else True)):
+            if not (3 <= W < n):
+                continue
+            bad, seen = cls._probe(A, W, 0x1FF, None)
+            if bad or not (seen & 16):
+                continue
+            umask = next((m for m in (0x0BA, 0x1BB, 0x0FE, 0x1FF) if not (seen & ~m)), None)
+            if umask is None or not _lib.lib().lmg_dia_smooth_supported(umask):
+                return None
+            self = cls()
+            self.n, self.W, self.umask = int(n), int(W), int(umask)
+            self.nslots = bin(umask).count("1")
+            self.dia = torch.empty(self.nslots * n, dtype=F64, device=A.vals.device)
+            bad, _seen = cls._probe(A, W, umask, self.dia)
+            if bad:
+                return None
+            self.bytes_ = 8 * self.nslots * n
+            return self
+        return None
+
+    def update_values(self, A):
+        """New values on the same pattern (Galerkin rebuild of a variable-coefficient level)."""
+        bad, _seen = self._probe(A, self.W, self.umask, self.dia)
+        return not bad
+
+    def bytes(self):
+        return int(self.bytes_)
+
+
 _PACKED_ENABLED = True
 _PATTERNS_ENABLED = True
 _STENCIL_ENABLED = True
 _GRID_MAPS_ENABLED = True
+_DIA_ENABLED = True
+
+
+def set_dia_enabled(flag):
+    """Whether pack() builds the DIA twin of variable-coefficient grid operators (default), i.e. whether their
+    smoothing steps run as fused passes (lmg_dia_smooth) or one launch per sweep (A/B runs and parity tests)."""
+    global _DIA_ENABLED
+    _DIA_ENABLED = bool(flag)
 
 
 def set_grid_maps_enabled(flag):
@@ -737,8 +819,12 @@ def set_tiled_enabled(flag):
 
 
 def _fused_kind(A):
-    """'reg' (stencil_fused.hip), 'tile' (stencil_tile.hip) or None: how stencil_smooth would run on A."""
+    """'reg' (stencil_fused.hip), 'tile' (stencil_tile.hip), 'dia' (dia_tile.hip: per-row values) or None: how
+    stencil_smooth would run on A."""
     S = getattr(A, "stencil", None)
+    D = getattr(A, "dia", None)
+    if S is None and D is not None and _PACKED_ENABLED and _DIA_ENABLED and _FUSED_ENABLED:
+        return "dia"
     if not (_PACKED_ENABLED and _STENCIL_ENABLED and _FUSED_ENABLED and S is not None):
         return None
     if S.n >= FUSED_MIN_ROWS:
@@ -772,6 +858,13 @@ def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None, prolong=None, r
     never written: lmg_stencil_smooth_restrict; see stencil_smooth_restrict_available)."""
     _vec_ok(x_in, b, x_out, r_out)
     S = A.stencil
+    if S is None and getattr(A, "dia", None) is not None:
+        D = A.dia
+        if prolong is not None or restrict is not None:
+            raise LmgError("stencil_smooth: transfers cannot be fused into the pass of a variable-coefficient operator")
+        check(_lib.lib().lmg_dia_smooth(D.n, D.W, D.umask, _p(D.dia), int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out),
+                                        _p(r_out), _s(D.dia)), "lmg_dia_smooth")
+        return
     if S is None:
         raise LmgError("stencil_smooth needs a grid-stencil matrix")
     hv = None if S._hot_val is None else ctypes.addressof(S._hot_val)
@@ -842,7 +935,7 @@ def stencil_smooth_prolong_available(A, P):
     T = getattr(P, "prolong", None)
     S = getattr(A, "stencil", None)
     kind = _fused_kind(A)
-    if not (_FUSED_PROLONG_ENABLED and T is not None and kind is not None and T.n == S.n and T.W == S.W):
+    if not (_FUSED_PROLONG_ENABLED and T is not None and kind in ("reg", "tile") and T.n == S.n and T.W == S.W):
         return False
     if kind == "tile":                   # the tile is loaded as x + P e: always cheaper than the P launch it replaces
         return True
@@ -869,7 +962,7 @@ def stencil_smooth_restrict_available(A, R):
     T = getattr(R, "restrict", None)
     S = getattr(A, "stencil", None)
     kind = _fused_kind(A)
-    if not (_FUSED_RESTRICT_ENABLED and T is not None and kind is not None and T.n == S.n and T.W == S.W):
+    if not (_FUSED_RESTRICT_ENABLED and T is not None and kind in ("reg", "tile") and T.n == S.n and T.W == S.W):
         return False
     if kind == "reg" and not (S.n >= FUSED_TRANSFER_MIN_ROWS and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask)):
         return False

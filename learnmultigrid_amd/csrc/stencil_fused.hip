@@ -784,7 +784,9 @@ int launch4(MArgs a, hipStream_t st)
     else a.segs = (a.lines + seg_lines - 1) / seg_lines;
     a.items = a.nb_strips * a.segs_b + (a.strips - a.nb_strips) * a.segs;
     const int grid = (a.items + kWavesPerBlock - 1) / kWavesPerBlock;
-    // (a prefetch distance of 3 lines was measured slower in the cycle -- 0.969 vs 0.933 ms -- and is not compiled)
+    // (deeper prefetch, measured round 3 on the scalarised kernel, 4097^2: 3 lines spills in the restricting pass, 0.238 ms;
+    // 6 lines at 2 waves / SIMD with 48 - 64-line segments 0.143 vs 0.149 ms with 2 lines and 28-line segments, the
+    // correcting pass unchanged -- a wave's step is bound by the dependent chain of its S + 1 stages, not by the loads)
     hipLaunchKernelGGL((stencil_fused_kernel<S, UM, RESID, ZERO, 2, PROL, REST>), dim3((unsigned)grid), dim3(kBlock), 0, st, a);
     LMG_CHECK_LAUNCH();
     return LMG_OK;

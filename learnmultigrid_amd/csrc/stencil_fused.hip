@@ -1018,7 +1018,8 @@ int lmg_stencil_smooth_restrict(int64_t n, int32_t line_stride, const uint8_t *p
     if ((const double *)b_coarse == x_in || b_coarse == x_out || (const double *)b_coarse == b) return LMG_ERR_ARG;
     // row (Y, X) of R sits on the fine node (2 Y, 2 X): every such node of the fine grid must have its coarse row
     const int64_t lines = n > 0 ? (n + line_stride - 1) / line_stride : 0;
-    if ((int64_t)coarse_stride < ((int64_t)line_stride + 1) / 2 || n_coarse < ((lines + 1) / 2 - 1) * coarse_stride + (line_stride + 1) / 2)
+    // -- and nothing else: the pass only writes b_coarse under those nodes, a larger coarse grid would keep stale rows
+    if ((int64_t)coarse_stride != ((int64_t)line_stride + 1) / 2 || (n % line_stride) != 0 || n_coarse != ((lines + 1) / 2) * coarse_stride)
         return LMG_ERR_ARG;
     MArgs a;
     const int rc = fill_args(a, n, line_stride, pid, npat, st_val, st_mask, union_mask, hot_pattern, h_hot_val, sweeps, x_in, b,

@@ -539,7 +539,8 @@ int lmg_stencil_smooth_tiled_restrict(int64_t n, int32_t line_stride, const uint
     if ((const double *)b_coarse == x_in || b_coarse == x_out || (const double *)b_coarse == b) return LMG_ERR_ARG;
     // every fine node (even line, even column) must have its coarse row
     const int64_t lines = n > 0 ? (n + line_stride - 1) / line_stride : 0;
-    if ((int64_t)coarse_stride < ((int64_t)line_stride + 1) / 2 || n_coarse < ((lines + 1) / 2 - 1) * coarse_stride + (line_stride + 1) / 2)
+    // -- and nothing else: the pass only writes b_coarse under those nodes, a larger coarse grid would keep stale rows
+    if ((int64_t)coarse_stride != ((int64_t)line_stride + 1) / 2 || (n % line_stride) != 0 || n_coarse != ((lines + 1) / 2) * coarse_stride)
         return LMG_ERR_ARG;
     TArgs a;
     const int rc = tile_args(a, n, line_stride, pid, npat, st_val, st_mask, union_mask, hot_pattern, h_hot_val, sweeps, x_in, b,

@@ -394,10 +394,8 @@ class DistributedVCycle:
                 wf, wc = math.isqrt(sizes[l]), math.isqrt(sizes[l + 1])
                 hint = (wf, wc) if (side is not None and wf * wf == sizes[l] and wc * wc == sizes[l + 1]) else None
                 for M in (d.R, d.P):
-                    try:
-                        M.pack(line_strides=hint)
-                    except TypeError:                     # (an ops module without the hint: tests' CPU shim)
-                        M.pack()
+                    # (DeviceCSR.pack is the same method whatever ops module drives the kernels: always takes the hint)
+                    M.pack(line_strides=hint)
         # ---- all-gather plumbing for the first replicated level ----------------------------------
         L = self.n_dist
         cb = self.bounds[L]

@@ -664,7 +664,9 @@ class RestrictTwin:
         if (ysh, xsh, xshl) != (0, 0, 1) or cs % 2 or Wc < 2 or shape[0] >= 2 ** 28:
             return None
         W = cs // 2
-        if W < 3 or 2 * Wc < W + 1:
+        # the fused passes write b_coarse only under fine nodes (even line, even column < W): the coarse grid must be
+        # exactly that set, or rows beyond it would keep the previous cycle's right-hand side
+        if W < 3 or Wc != (W + 1) // 2 or shape[1] % W or int(R.n) != ((shape[1] // W + 1) // 2) * Wc:
             return None
         ptr = R.pat_ptr.cpu().numpy()
         off = R.pat_off.cpu().numpy().astype(np.int64)[: R.nent]
@@ -806,6 +808,8 @@ FUSED_MAX_SWEEPS = 3
 # the 2049^2 level on the tiled pass: 0.788 -> 0.766 ms.  The crossover lies between 9.4 M rows (5-point 3073^2: cycle 0.448 ms tiled,
 # 0.459 register) and 16.8 M (5-point 4097^2: 0.65 vs 0.77; 9-point: 1.905 vs 1.913 at 8193^2 / 7 levels, i.e. equal).
 FUSED_MIN_ROWS = 12_000_000
+REG_MAX_ROWS = (1 << 29) - 4096      # lmg_stencil_smooth* (32-bit byte offsets); lmg_stencil_gs_sweep: (1 << 29) - 8192
+GS_WAVE_MAX_ROWS = (1 << 29) - 8192
 # The tiled pass takes over below, down to levels that are a handful of workgroups either way.
 TILED_MIN_ROWS = 4096
 _TILED_ENABLED = True
@@ -828,7 +832,8 @@ def _fused_kind(A):
     if not (_PACKED_ENABLED and _STENCIL_ENABLED and _FUSED_ENABLED and S is not None):
         return None
     if S.n >= FUSED_MIN_ROWS:
-        return "reg" if _lib.lib().lmg_stencil_smooth_supported(S.umask) else None
+        # (the register pass addresses with 32-bit byte offsets: beyond REG_MAX_ROWS the separate sweeps run)
+        return "reg" if (S.n < REG_MAX_ROWS and _lib.lib().lmg_stencil_smooth_supported(S.umask)) else None
     if _TILED_ENABLED and S.n >= TILED_MIN_ROWS and S.W >= 3 and _lib.lib().lmg_stencil_smooth_tiled_supported(S.umask):
         return "tile"
     return None
@@ -1184,7 +1189,8 @@ def set_wavefront_gs_enabled(flag):
 
 def stencil_gs_available(A):
     S = getattr(A, "stencil", None)
-    return bool(_PACKED_ENABLED and _STENCIL_ENABLED and _WAVE_GS_ENABLED and S is not None and S.gs_ok)
+    return bool(_PACKED_ENABLED and _STENCIL_ENABLED and _WAVE_GS_ENABLED and S is not None and S.gs_ok
+                and S.n < GS_WAVE_MAX_ROWS)
 
 
 def stencil_gs(A, x, b, sweeps=1):

@@ -1238,6 +1238,41 @@ def test_fused_pre_smoothing_with_the_restriction_folded_in(m, kind, seg_lines):
         ops.set_tiled_enabled(True)
 
 
+def test_tiled_post_smoothing_eight_wave_variant_against_the_oracle():
+    """Grids of >= 768 lines run the correcting tiled pass on 8-wave workgroups of four lines per wave
+    (stencil_tile_kernel<..., PROL, RBV = 4>: level 1 of cfg#4).  That instantiation against the oracle's prolongation +
+    S Jacobi sweeps directly, bitwise -- 5-point 769^2 and the 9-point Galerkin operator of a 1537^2 grid -- and the
+    4-line-per-wave variant forced on a small grid as well."""
+    for side, kind in ((769, "5pt"), (769, "9pt"), (257, "5pt")):
+        if kind == "5pt":
+            A = K.as_csr(P.poisson_2d_structured(side - 1)[0])
+        else:
+            Af = P.poisson_2d_structured(2 * (side - 1))[0]
+            Pf = P.tensor_interpolator_2d(2 * (side - 1) + 1)
+            A = K.as_csr(sp.csr_matrix(Pf.T @ Af @ Pf))
+        Pm = K.as_csr(sp.csr_matrix(P.tensor_interpolator_2d(side)))
+        n, nc = A.shape[0], Pm.shape[1]
+        dA = ops.DeviceCSR.from_scipy(A, DEV)
+        dA.pack()
+        dP = ops.DeviceCSR.from_scipy(Pm, DEV)
+        dP.pack()
+        assert ops._fused_kind(dA) == "tile" and ops.stencil_smooth_prolong_available(dA, dP)
+        rng = np.random.default_rng(side)
+        x0, b, e = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(nc)
+        old = ops.tune_get("tile_prol_wide_lines")
+        try:
+            ops.tune_set("tile_prol_wide_lines", 0 if side < 768 else old)       # small grid: force the wide variant
+            assert side >= ops.tune_get("tile_prol_wide_lines")
+            want = K.spmv(Pm, e, x0.copy(), 1.0, 1.0)
+            for S in (1, 2, 3):
+                want = K.jacobi(A, want, b, 0.8)
+                out = torch.full((n,), np.nan, dtype=torch.float64, device=DEV)
+                ops.stencil_smooth(dA, dev(x0), dev(b), 0.8, S, out, None, prolong=(dP, dev(e)))
+                assert np.array_equal(out.cpu().numpy(), want), (side, kind, S)
+        finally:
+            ops.tune_set("tile_prol_wide_lines", old)
+
+
 def test_prolong_twin_only_for_two_by_two_window_transfers():
     """ProlongTwin.from_patterns accepts the tensor-product interpolation and nothing wider: an L2-type
     transfer (3-point rows per axis) keeps its own launch."""

@@ -420,6 +420,67 @@ def test_full_size_properties_4097():
     assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(bc.cpu().numpy(), wbc)
 
 
+def test_cfg4_history_4097_six_levels_against_the_oracle():
+    """cfg#4 itself -- 4097^2, 6 levels, V(3,3) weighted Jacobi, what bench.py times -- against the CPU oracle's
+    hoisted cycle (oracle/vcycle_ref.py: R = P^T, Galerkin products and the coarse LU once, then the reference's
+    arithmetic per cycle): five residual norms at 1e-10 relative (north_star's bar), ~10 s of CPU."""
+    m, levels = 4096, 6
+    A, rhs = P.poisson_2d_structured(m)
+    hier = P.geometric_hierarchy_2d(m + 1, levels)
+    mg = HierarchyMG(A, rhs.copy(), hier)
+    mg.solve(levels=levels, smoother="Jacobi", smooth_steps=3, max_iterations=6, error=1e-30,
+             smoother_semantics="as_named", omega=0.8, use_graph=True)
+    got = mg.get_track_res().ravel()
+    ref = V.HoistedVCycle(A, hier)
+    b = rhs.ravel()
+    x = np.zeros(A.shape[0])
+    want = []
+    for _ in range(6):
+        want.append(np.linalg.norm(b - A @ x))
+        x = ref.cycle(x, b, "Jacobi", 3, 0.8)
+    want = np.array(want)
+    # (entry 0 of the solver's track is the sqrt(n) quirk of Multigrid.py:64-66)
+    assert got[0] == np.sqrt(float(A.shape[0]))
+    np.testing.assert_allclose(got[1:], want[1:], rtol=RTOL, atol=1e-14 * want.max())
+    xs = x_after(ref, b, 5)
+    np.testing.assert_allclose(mg.get_solution().ravel(), xs, rtol=0, atol=1e-9 * np.abs(xs).max())
+
+
+def x_after(ref, b, cycles):
+    x = np.zeros(b.size)
+    for _ in range(cycles):
+        x = ref.cycle(x, b, "Jacobi", 3, 0.8)
+    return x
+
+
+def test_a_timed_out_wavefront_band_raises_instead_of_returning_a_wrong_iterate():
+    """gs_wave.hip turns a stalled band into a wrong result and sets a sticky flag once its spin budget runs out; the
+    solvers read the flag where they synchronise anyway (after the residual norm of each outer iteration) and raise."""
+    from learnmultigrid_amd import ops
+    from learnmultigrid_amd._lib import LmgError
+    m = 256
+    A, rhs = P.poisson_2d_structured(m)
+    mg = HierarchyMG(A, rhs.copy(), P.geometric_hierarchy_2d(m + 1, 3))
+    kw = dict(levels=3, smoother="GaussSeidel", smooth_steps=2, max_iterations=3, error=1e-30)
+    mg.solve(**kw)                                             # as shipped: forward Gauss-Seidel on every level
+    lev0 = mg._hier.levels[0].A
+    assert ops.stencil_gs_available(lev0) and lev0.stencil._gs_work is not None
+    ops.stencil_gs_check(lev0)                                 # clean run: nothing raised
+    lev0.stencil._gs_work.view(torch.int32)[0] = 1             # what a timed-out band leaves behind
+    try:
+        with pytest.raises(LmgError):
+            mg.solve(**kw)
+        g = GaussSeidel(A, rhs.copy())
+        g.solve(max_iterations=1)
+        dm = g._device_matrix()
+        if dm.stencil is not None and dm.stencil._gs_work is not None:
+            dm.stencil._gs_work.view(torch.int32)[0] = 1
+            with pytest.raises(LmgError):
+                g.solve(max_iterations=2)
+    finally:
+        lev0.stencil._gs_work.view(torch.int32)[0] = 0
+
+
 def test_g6_cg_matches_reference():
     from learnmultigrid_amd.solvers import CG
     g = load_golden("g6_cg_ne64")

@@ -317,6 +317,10 @@ int lmg_pcsr_tile_colrange(int64_t n, int32_t tile_rows, const int32_t *d_rowptr
                            int32_t *d_cmin, int32_t *d_cmax, void *stream);
 int lmg_pcsr_encode_cols16(int64_t n, int32_t tile_rows, const int32_t *d_rowptr, const int32_t *d_colidx,
                            const int32_t *d_colbase, uint16_t *d_out, void *stream);
+/* the occupied slots of that table, appended in ANY order to d_out (at most cap of them; *d_count, zeroed by the caller,
+ * receives how many there were): the few survivors are sorted on the host */
+int lmg_value_set_collect(const uint64_t *d_table, int64_t table_slots, uint64_t *d_out, int32_t cap, int32_t *d_count,
+                          void *stream);
 int lmg_value_set_insert(int64_t count, const double *d_vals, uint64_t *d_table, int64_t table_slots,
                          int32_t limit, int32_t *d_state, void *stream);
 int lmg_value_encode(int64_t count, const double *d_vals, const double *d_dict, int32_t ndict, int width,

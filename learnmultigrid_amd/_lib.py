@@ -67,6 +67,7 @@ SIGNATURES = {
     "lmg_sell_fill": (_c.c_int, [_i64, _p, _p, _p, _p, _p, _c.c_int, _p, _p, _p]),
     "lmg_pcsr_tile_colrange": (_c.c_int, [_i64, _i32, _p, _p, _p, _p, _p]),
     "lmg_pcsr_encode_cols16": (_c.c_int, [_i64, _i32, _p, _p, _p, _p, _p]),
+    "lmg_value_set_collect": (_c.c_int, [_p, _i64, _p, _i32, _p, _p]),
     "lmg_value_set_insert": (_c.c_int, [_i64, _p, _p, _i64, _i32, _p, _p]),
     "lmg_value_encode": (_c.c_int, [_i64, _p, _p, _i32, _c.c_int, _p, _p, _p]),
     "lmg_csr_inverse_diagonal": (_c.c_int, [_i64, _p, _p, _p, _p, _p]),

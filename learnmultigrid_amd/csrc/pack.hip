@@ -173,6 +173,20 @@ inline int grid_for(int64_t work_items, int per_block, int cap)
 
 }  // namespace
 
+// the occupied slots of the table, appended in any order to `out` (at most `cap`); d_count: how many there were
+__global__ void __launch_bounds__(256) value_set_collect_kernel(const unsigned long long *table, long long slots,
+                                                                       unsigned long long *out, int cap, int *count)
+{
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < slots; i += stride) {
+        const unsigned long long k = table[i];
+        if (k != ~0ull) {
+            const int at = atomicAdd(count, 1);
+            if (at < cap) out[at] = k;
+        }
+    }
+}
+
 extern "C" {
 
 int lmg_pcsr_tile_colrange(int64_t n, int32_t tile_rows, const int32_t *d_rowptr, const int32_t *d_colidx,
@@ -197,6 +211,19 @@ int lmg_pcsr_encode_cols16(int64_t n, int32_t tile_rows, const int32_t *d_rowptr
     const int64_t ntile = (n + tile_rows - 1) / tile_rows;
     encode_cols16_kernel<<<grid_for(ntile, 1, 1 << 20), kPackBlock, 0, lmg_stream(stream)>>>(
         n, tile_rows, ntile, d_rowptr, d_colidx, d_colbase, d_out);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
+int lmg_value_set_collect(const uint64_t *d_table, int64_t table_slots, uint64_t *d_out, int32_t cap, int32_t *d_count,
+                          void *stream)
+{
+    if (table_slots < 1 || cap < 0 || !d_table || !d_out || !d_count) return LMG_ERR_ARG;
+    int64_t grid = (table_slots + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    value_set_collect_kernel<<<(unsigned)grid, 256, 0, lmg_stream(stream)>>>(
+        reinterpret_cast<const unsigned long long *>(d_table), (long long)table_slots,
+        reinterpret_cast<unsigned long long *>(d_out), cap, d_count);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }

@@ -205,6 +205,18 @@ __device__ __forceinline__ void apply_rows_hot(const double (&hv)[9], const d2 &
     }
 }
 
+#ifdef LMG_FUSED_TRACE
+// probe builds (tools/probe/fused_wavetime.hip): cycle counter of the wave of item LMG_FUSED_TRACE at eight points of
+// each of its first 64 steps (0 step start, 1 line arrived, 2 next line requested, 3.. after each stage, 7 step end)
+__device__ unsigned long long g_fused_trace[64 * 8];
+__device__ int g_fused_trace_item;
+#define LMG_TRACE(slot)                                                                                   \
+    do {                                                                                                  \
+        if (FAST && trace_me && (t - y_begin) < 64) g_fused_trace[(t - y_begin) * 8 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define LMG_TRACE(slot)
+#endif
 #ifdef LMG_FUSED_WAVETIME
 __device__ unsigned long long g_fused_wavetime[2 * LMG_FUSED_WAVETIME];   // probe builds (tools/probe/fused_wavetime.hip): start / end (100 MHz) of every wave
 #endif
@@ -452,10 +464,15 @@ __device__ __forceinline__ void fused_march(const MArgs &a, const Tables &T, con
     for (int u = 0; u < PF; ++u) fetch(y_begin + u, pre[u]);
 
     const int t_last = out_y1 - 1 + S + (RESID ? 1 : 0) + (REST ? 1 : 0);   // last step that still produces output
+#ifdef LMG_FUSED_TRACE
+    const bool trace_me = lane == 0 && strip == g_fused_trace_item / 100000 && out_y0 <= g_fused_trace_item % 100000 &&
+                          g_fused_trace_item % 100000 < out_y1;            // (strip * 100000 + a line of the segment)
+#endif
     for (int tb = y_begin; tb <= t_last; tb += kUF) {
 #pragma unroll
         for (int u = 0; u < kUF; ++u) {
             const int t = tb + u;
+            LMG_TRACE(0);
             // ---- line t arrives ------------------------------------------------------------------
             const int q0 = u % kNBR;
             {
@@ -526,7 +543,9 @@ __device__ __forceinline__ void fused_march(const MArgs &a, const Tables &T, con
                 Pq[q0] = FAST ? L.praw : ((okA ? pa : 0) | ((okB ? pb : 0) << 8) | ((L.ok & 3) << 16));
                 Hq[q0] = __all(Pq[q0] == hot2);
             }
+            LMG_TRACE(1);
             fetch(t + PF, pre[u % PF]);
+            LMG_TRACE(2);
             // ---- stages 1..S: iterate s on line t - s -----------------------------------------------
 #pragma unroll
             for (int s = 1; s <= S; ++s) {
@@ -568,6 +587,7 @@ __device__ __forceinline__ void fused_march(const MArgs &a, const Tables &T, con
                 }
                 X[s][xc] = nx;
                 if (s == S) store2(rs_out, a.out, t - S, p2, nx.x, nx.y);
+                LMG_TRACE(2 + s);
             }
             // ---- residual of the final iterate on line t - S - 1 ---------------------------------------
             if (RESID) {
@@ -655,6 +675,7 @@ __device__ __forceinline__ void fused_march(const MArgs &a, const Tables &T, con
                     }
                 }
             }
+            LMG_TRACE(7);
         }
     }
 }

@@ -141,15 +141,17 @@ class DeviceCSR:
         """Any scipy.sparse matrix / ndarray -> sorted, duplicate-free CSR on `device`
         (the form pyamg hands its kernel after the CSC->CSR conversion, Multigrid.py:88)."""
         import scipy.sparse as sp
-        A = sp.csr_matrix(A, dtype=np.float64)
-        if canonical and not A.has_canonical_format:
+        if not (sp.isspmatrix_csr(A) and A.dtype == np.float64):
+            A = sp.csr_matrix(A, dtype=np.float64)
+        if canonical and not A.has_canonical_format:          # (SciPy caches the answer on the matrix object)
             A = A.copy()
             A.sum_duplicates()
         if A.nnz >= 2 ** 31 - 8192 or max(A.shape) >= 2 ** 31 - 1:
             raise ValueError("matrix too large for int32 indices")
-        return cls(torch.from_numpy(A.indptr.astype(np.int32)).to(device),
-                   torch.from_numpy(A.indices.astype(np.int32)).to(device),
-                   torch.from_numpy(np.ascontiguousarray(A.data)).to(device), A.shape)
+        # (no host copies: SciPy holds int32 indices at these sizes already)
+        return cls(torch.from_numpy(np.ascontiguousarray(A.indptr, dtype=np.int32)).to(device),
+                   torch.from_numpy(np.ascontiguousarray(A.indices, dtype=np.int32)).to(device),
+                   torch.from_numpy(np.ascontiguousarray(A.data, dtype=np.float64)).to(device), A.shape)
 
     def transpose(self):
         """A^T as a sorted CSR on the same device (setup: R = P^T).  A stable sort by column
@@ -232,12 +234,21 @@ class PackedCSR:
         st = state.cpu()
         if int(st[1]):
             return None
-        keys = table[table != -1]
-        if int(st[2]):
-            keys = torch.cat([keys, torch.full((1,), -1, dtype=torch.int64, device=dev)])
-        if keys.numel() > limit:
+        # the few survivors: collected by an own kernel, sorted on the host (a library sort / mask / cat each cost
+        # 50 - 75 ms of code-object loading in a fresh process)
+        cap = limit + 8
+        out = torch.empty(cap, dtype=torch.int64, device=dev)
+        cnt = torch.zeros(1, dtype=I32, device=dev)
+        check(L.lmg_value_set_collect(_p(table), cls._VSET_SLOTS, _p(out), cap, _p(cnt), _s(vals)), "lmg_value_set_collect")
+        k = int(cnt.cpu()[0])
+        if k > cap:
             return None
-        return torch.sort(keys).values.contiguous()
+        keys = out[:k].cpu().numpy()
+        if int(st[2]):
+            keys = np.concatenate([keys, np.array([-1], dtype=np.int64)])
+        if keys.size > limit:
+            return None
+        return torch.from_numpy(np.sort(keys)).to(dev)
 
     @staticmethod
     def _encode_values(vals, uniq, width, out):
@@ -459,10 +470,13 @@ class RowPatterns:
         del hashes
         rep = torch.full((256,), -1, dtype=I32, device=dev)
         check(L.lmg_rpat_claim(n, _p(pid), _p(rep), _s(pid)), "lmg_rpat_claim")
-        rep = rep[:npat].long()
-        if int(rep.min()) < 0:
+        # (the pattern table is a few hundred numbers: index gathers on the device, the arithmetic on the host -- every
+        # library elementwise kernel used for the first time costs 50 - 75 ms of code-object loading)
+        rep_h = rep[:npat].cpu().numpy().astype(np.int64)
+        if npat == 0 or rep_h.min() < 0:
             return None
-        starts, ends = A.rowptr[rep].cpu().numpy().astype(np.int64), A.rowptr[rep + 1].cpu().numpy().astype(np.int64)
+        rep = torch.from_numpy(rep_h).to(dev)
+        starts, ends = A.rowptr[rep].cpu().numpy().astype(np.int64), A.rowptr[torch.from_numpy(rep_h + 1).to(dev)].cpu().numpy().astype(np.int64)
         lens = ends - starts
         nent = int(lens.sum())
         if nent > max_ent:
@@ -477,8 +491,14 @@ class RowPatterns:
         ptr = np.zeros(npat + 1, dtype=np.int32)
         np.cumsum(lens, out=ptr[1:])
         self.pat_ptr = torch.from_numpy(ptr).to(dev)
-        base_of = torch.from_numpy(cls.grid_base(grid_map, np.repeat(rep.cpu().numpy(), lens).astype(np.int64))).to(dev)
-        self.pat_off = (A.colidx[d_idx].long() - base_of).to(I32).contiguous() if nent else torch.zeros(1, dtype=I32, device=dev)
+        base_of = cls.grid_base(grid_map, np.repeat(rep_h, lens).astype(np.int64))
+        if nent:
+            off_h = A.colidx[d_idx].cpu().numpy().astype(np.int64) - base_of
+            if np.abs(off_h).max() >= 2 ** 31:
+                return None
+            self.pat_off = torch.from_numpy(off_h.astype(np.int32)).to(dev)
+        else:
+            self.pat_off = torch.zeros(1, dtype=I32, device=dev)
         self.pat_val = A.vals[d_idx].contiguous() if nent else torch.zeros(1, dtype=F64, device=dev)
         mismatch = torch.zeros(1, dtype=I32, device=dev)
         check(L.lmg_rpat_verify_grid(n, A.shape[1], gmp, _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(pid), npat,
@@ -503,7 +523,7 @@ class StencilTwin:
     from_patterns returns None for everything that does not fit (the RPAT kernel then runs)."""
 
     __slots__ = ("n", "W", "npat", "pid", "st_val", "st_mask", "umask", "bytes_", "patterns", "hot", "_hot_val",
-                 "gs_ok", "_gs_work")
+                 "_gs_ok", "_gs_work")
 
     @staticmethod
     def _decompose(off, W):
@@ -568,18 +588,29 @@ class StencilTwin:
             counts = _pid_counts(R) if len(cand) > 1 else None
             self.hot = int(cand[0] if counts is None else max(cand, key=lambda p: counts[p]))
             self._hot_val = (ctypes.c_double * 9)(*[float(v) for v in st_val[self.hot * 9: self.hot * 9 + 9]])
-        # wavefront Gauss-Seidel (lmg_stencil_gs_sweep) needs a supported slot set and no coupling across the
-        # ends of a line: rows in column 0 must not reach column - 1, rows in column W - 1 not column + 1
+        # wavefront Gauss-Seidel (lmg_stencil_gs_sweep): see gs_ok below (decided on first use)
         self._gs_work = None
-        # (1-D chains are one lane of the wavefront kernel; the one-wave chain executor of gs.hip, x in LDS, is
-        # faster there: 0.29 vs 0.5 us per row)
-        self.gs_ok = bool(_lib.lib().lmg_stencil_gs_supported(self.umask)) and self.n >= 2 and bool(self.umask & 0x1C7)
-        if self.gs_ok:
-            mk = self.st_mask
-            first = mk[R.pid[0::W].long()]
-            last = mk[R.pid[W - 1::W].long()]
-            self.gs_ok = not bool(((first & 0x49) != 0).any()) and not bool(((last & 0x124) != 0).any())
+        self._gs_ok = None
         return self
+
+    @property
+    def gs_ok(self):
+        """Whether the wavefront Gauss-Seidel kernel may run on this operator: a supported slot set and no coupling
+        across the ends of a line -- rows in column 0 must not reach column - 1, rows in column W - 1 not column + 1.
+        Decided on first use (a few library elementwise kernels on the ids of two grid columns: their code objects
+        cost 0.13 s to load in a fresh process, which a Jacobi-only run never needs).
+        (1-D chains are one lane of the wavefront kernel; the one-wave chain executor of gs.hip, x in LDS, is
+        faster there: 0.29 vs 0.5 us per row)"""
+        if self._gs_ok is None:
+            ok = bool(_lib.lib().lmg_stencil_gs_supported(self.umask)) and self.n >= 2 and bool(self.umask & 0x1C7)
+            if ok:
+                mk = self.st_mask.cpu().numpy()
+                W = self.W
+                first = mk[self.pid[0::W].cpu().numpy()]
+                last = mk[self.pid[W - 1::W].cpu().numpy()]
+                ok = not bool(((first & 0x49) != 0).any()) and not bool(((last & 0x124) != 0).any())
+            self._gs_ok = ok
+        return self._gs_ok
 
     def bytes(self):
         return int(self.bytes_)

@@ -90,7 +90,11 @@ def _worker(rank, world, port, m, levels, replicate_below, steps, halo_depth, ou
                 "cuts_on_lines": all(c % sd == 0 for l, sd in enumerate(P.level_sizes(side, D.n_dist + 1))
                                      for c in D.bounds[l]),
                 "ghosts": [d.n_lo + d.n_hi for d in D.dl],
-                "neighbours": [sorted(q for q, _o, _c in d.recv) for d in D.dl]}
+                "neighbours": [sorted(q for q, _o, _c in d.recv) for d in D.dl],
+                # the exchange plan of every level: (peer, number of values) of every message
+                "send": [sorted((int(q), int(idx[1] - idx[0]) if isinstance(idx, tuple) else int(idx.numel())) for q, idx, _b in d.send)
+                         for d in D.dl],
+                "recv": [sorted((int(q), int(c)) for q, _o, c in d.recv) for d in D.dl]}
         with pytest.raises(ValueError):
             D.cycle("GaussSeidel", 1, 1.0)
         np.save(os.path.join(out_dir, "info_%d.npy" % rank), np.array([repr(info)]))
@@ -111,8 +115,14 @@ def test_distributed_vcycle_matches_single_process(tmp_path, world, m, levels, r
     port = _free_port()
     mp.spawn(_worker, args=(world, port, m, levels, replicate_below, steps, halo_depth, str(tmp_path)),
              nprocs=world, join=True)
+    infos = [eval(str(np.load(os.path.join(str(tmp_path), "info_%d.npy" % r))[0])) for r in range(world)]
+    # every message has its counterpart: rank r sends c values to q on level l  <=>  q expects c values from r
+    for l in range(infos[0]["n_dist"]):
+        sends = sorted((r, q, c) for r in range(world) for q, c in infos[r]["send"][l])
+        recvs = sorted((q, r, c) for r in range(world) for q, c in infos[r]["recv"][l])
+        assert sends == recvs, (l, sends, recvs)
     for r in range(world):
-        info = eval(str(np.load(os.path.join(str(tmp_path), "info_%d.npy" % r))[0]))
+        info = infos[r]
         assert info["bit_identical"], info
         assert info["norm_rel"] < 1e-13, info
         assert info["contracting"], info

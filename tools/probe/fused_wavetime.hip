@@ -34,6 +34,9 @@ int main(int argc, char **argv)
     (void)hipMemcpy(dval, st_val, sizeof st_val, hipMemcpyHostToDevice);
     (void)hipMemcpy(dmask, st_mask, sizeof st_mask, hipMemcpyHostToDevice);
     lmg_fused_tune_set("fused_seg_lines", seg);
+#ifdef LMG_FUSED_TRACE
+    { int item = argc > 5 ? atoi(argv[5]) : 17 * 100000 + 2000; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fused_trace_item), &item, sizeof item); }
+#endif
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     for (int rep = 0; rep < 4; ++rep) {
         (void)hipEventRecord(e0);
@@ -66,6 +69,18 @@ int main(int argc, char **argv)
         printf("%-17s %5zu waves: duration min %.1f med %.1f p90 %.1f max %.1f us | start med %.1f max %.1f | end med %.1f p90 %.1f max %.1f\n",
                names[c], m, dur[0], dur[m / 2], dur[m * 9 / 10], dur[m - 1], start[m / 2], start[m - 1], end[m / 2], end[m * 9 / 10], end[m - 1]);
     }
+#ifdef LMG_FUSED_TRACE
+    {
+        unsigned long long tr[64 * 8];
+        (void)hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_fused_trace), sizeof tr);
+        printf("traced wave, cycles per step: wait+arrive | issue loads | stage1 | stage2 | stage3 | resid etc. | step total\n");
+        for (int k = 0; k < 40 && tr[k * 8 + 7]; ++k) {
+            unsigned long long *r = tr + k * 8;
+            printf("%2d: %6llu %6llu %6llu %6llu %6llu %6llu | %6llu\n", k, r[1] - r[0], r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4],
+                   r[7] - r[5], k + 1 < 64 && tr[(k + 1) * 8] ? tr[(k + 1) * 8] - r[0] : 0ull);
+        }
+    }
+#endif
     // histogram of wave end times (10 bins)
     int hist[10] = {0};
     for (int i = 0; i < items; ++i) hist[std::min(9, (int)((wt[2 * i + 1] - t0) * 10 / (t1 - t0 + 1)))]++;

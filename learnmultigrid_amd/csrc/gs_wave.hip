@@ -23,6 +23,7 @@
 // Same row arithmetic in the same order as gs_update_row (rsum over the off-diagonal entries in column order,
 // (b - rsum) / diag, rows with a zero diagonal untouched): bit-identical to the level-scheduled sweep and to
 // the CPU oracle.  4097^2: one sweep ~1.5 ms instead of 43.7 ms (8191 launches); 513^2 ~0.25 ms instead of 2.5.
+#include <math.h>
 #include <string.h>
 #include "lmg_common.hpp"
 
@@ -55,6 +56,7 @@ struct GArgs {
     const double *b;
     int hot;                                // interior pattern (all union slots, non-zero diagonal) or -1
     double hot_val[9];
+    double hot_rcp;                         // 1 / hot_val[4] when that diagonal is a power of two (the quotient is then a product, bit for bit), else 0
     int sweeps;                             // sweeps of this launch (<= kMaxSweeps), pipelined: see gs_wavefront_kernel
     int *work;                              // [0] error flag, [1] ticket, [2] where the other lanes "publish",
                                             // [3 + s * nbands + k] columns done on the last line of band k in sweep s
@@ -310,6 +312,276 @@ __global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
     __hip_atomic_store(prog_mine, W, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- the same sweep with the band's data staged through LDS --------------------------------------------------------
+// gs_wavefront_kernel issues, per iteration, five vector-memory instructions whose 64 lanes sit in 64 different grid
+// lines (one cache line each): ~1 us per anti-diagonal, all of it address processing.  Here the band's lines travel in
+// CHUNKS of 16 columns: every chunk is brought in by LDS-DMA (global_load_lds: 8 grid lines x 128 B per instruction,
+// each lane group a whole cache line), a
+// ring of 8 chunk slots (65 lines of x, 64 of b, the pattern ids, the last line of the band above) holds the window the
+// 64 skewed lanes work in, results are written back INTO the tile and a finished chunk leaves by 8 coalesced stores.
+// A step then touches LDS only; the band above is waited for once per chunk (its progress counter now counts flushed
+// chunks).  Single sweeps of operators without the upper-right slot (5-point, 7-point: lane l relaxes column t - l).
+// Same row arithmetic in the same order as gs_wavefront_kernel: bit-identical.
+constexpr int kCW = 16;                                    // columns per chunk
+constexpr int kNCH = 8;                                    // ring slots
+constexpr int kXSBytes = 72 * 128;                         // x: 9 groups of 8 lines (65 used) x 16 columns
+constexpr int kBSBytes = 64 * 128;
+constexpr int kPSBytes = 5 * 256;                          // pattern ids: 5 aligned dwords per line, [dword][line]
+constexpr int kUSBytes = 128;                              // the last line of the band above
+constexpr int kSlotBytes = kXSBytes + kBSBytes + kPSBytes + kUSBytes;
+constexpr int kLead = 2;                                   // chunks requested ahead of lane 0
+constexpr int kFlushLag = 5;                               // chunk p - 5 is complete (lane 63 has left it) when lane 0 enters chunk p
+
+#define LMG_GLDS(gptr, lptr, bytes, aux)                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                  \
+                                     (__attribute__((address_space(3))) void *)(lptr), bytes, 0, aux)
+
+template <unsigned UM>
+__global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
+{
+    static_assert(!(UM & 4u), "bands staged through LDS: operators without the upper-right slot");
+    __shared__ __attribute__((aligned(16))) unsigned char s_tile[kNCH * kSlotBytes];
+    __shared__ double s_val[kMaxPat * 9];
+    __shared__ int s_mask[kMaxPat];
+    __shared__ int s_band;
+    const int lane = threadIdx.x;
+    for (int i = lane; i < a.npat * 9; i += 64) s_val[i] = a.st_val[i];
+    for (int i = lane; i < a.npat; i += 64) s_mask[i] = a.st_mask[i];
+    if (lane == 0) s_band = atomicAdd(&a.work[1], 1);
+    __syncthreads();
+    const int band = __builtin_amdgcn_readfirstlane(s_band);
+    if (band >= a.nbands) return;
+
+    const int n = a.n, W = a.W;
+    const int y0 = band * 64;
+    const int y = y0 + lane;
+    const bool line_ok = y < a.lines;
+    const int last_lane = min(63, a.lines - 1 - y0);
+    const int cmax = (W - 1) / kCW;                                   // last chunk
+    int *const prog = a.work + 3;
+    const int *prog_prev = band > 0 ? prog + band - 1 : a.work;
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a.x, 0, (int)((unsigned)n * 8u), 0x00020000);
+
+    // ---- LDS addressing: plain rows of 128 B.  Lane l reads row l at column t - l: the SKEW of the wavefront spreads the
+    // 64 lanes over the banks by itself (30 l + 2 t mod 64 dwords: conflict-free; an XOR swizzle of the pieces made it 5x worse)
+    const unsigned rowoff = (unsigned)lane * 128u, frow = 0u;
+    const unsigned rowoff1 = (unsigned)(lane + 1) * 128u, frow1 = 0u;
+    auto taddr = [&](unsigned roff, unsigned f, int col) -> unsigned {
+        return (((unsigned)col >> 4) & (kNCH - 1)) * kSlotBytes + roff + ((((unsigned)col >> 1) & 7u) ^ f) * 16u + ((unsigned)col & 1u) * 8u;
+    };
+    const unsigned palign = (unsigned)(((int64_t)y * W) & 3);         // byte misalignment of the lane's line in the id array
+    auto ldsd = [&](unsigned off) -> double { return *reinterpret_cast<const double *>(s_tile + off); };
+
+    // ---- chunk c comes in: 9 + 8 instructions of 8 lines x 128 B, 5 dwords of ids per line, the line above -------------
+    auto issue_up = [&](int c) {                                      // the last line of the band above, columns of chunk c
+        if (c > cmax || band == 0) return;
+        if (lane < 8) {
+            const int64_t idx = (int64_t)(y0 - 1) * W + c * kCW + 2 * lane;
+            LMG_GLDS(a.x + idx, s_tile + (c & (kNCH - 1)) * kSlotBytes + kXSBytes + kBSBytes + kPSBytes, 16, kSc1);   // written write-through there
+        }
+    };
+    auto issue_chunk = [&](int c, bool with_up) {
+        if (c > cmax) return;                                         // uniform
+        unsigned char *sb = s_tile + (c & (kNCH - 1)) * kSlotBytes;
+        const int col0 = c * kCW;
+        const int r = lane >> 3, q = lane & 7;
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+            const int row = 8 * g + r;
+            const int pce = q;
+            const int64_t idx = (int64_t)(y0 + row) * W + col0 + 2 * pce;
+            // (a piece that straddles the end of the vector is 16-byte aligned: the vectors are, and n - 1 is even there)
+            if (row <= 64 && y0 + row < a.lines && idx < n) LMG_GLDS(a.x + idx, sb + g * 1024, 16, 0);
+            if (g < 8 && y0 + row < a.lines && idx < n) LMG_GLDS(a.b + idx, sb + kXSBytes + g * 1024, 16, 0);
+        }
+        if (line_ok) {
+            const unsigned char *src = a.pid + ((int64_t)y * W - palign) + col0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) LMG_GLDS(src + 4 * k, sb + kXSBytes + kBSBytes + k * 256, 4, 0);
+        }
+        if (with_up) issue_up(c);
+    };
+    // ---- chunk fc leaves: 8 lines x 128 B per store instruction; the band's last line write-through ----------------------
+    auto flush_chunk = [&](int fc) {
+        if (fc < 0 || fc > cmax) return;
+        const unsigned char *sb = s_tile + (fc & (kNCH - 1)) * kSlotBytes;
+        const int col0 = fc * kCW;
+        const int r = lane >> 3, q = lane & 7;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (8 * g > last_lane) break;                             // uniform
+            const int row = 8 * g + r;
+            const int col = col0 + 2 * q;
+            const u4 v = *reinterpret_cast<const u4 *>(sb + g * 1024 + lane * 16);
+            const int64_t i = (int64_t)(y0 + row) * W + col;
+            const bool rok = row <= last_lane;
+            const unsigned off16 = (rok && col + 1 < W) ? (unsigned)i * 8u : kOOB;
+            const unsigned off8 = (rok && col + 1 == W) ? (unsigned)i * 8u : kOOB;
+            u2 v2;
+            v2.x = v.x;
+            v2.y = v.y;
+            if (g == (last_lane >> 3)) {                              // uniform: the group with the line the next band reads
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_x, off16, 0, kSc1);
+                __builtin_amdgcn_raw_buffer_store_b64(v2, rs_x, off8, 0, kSc1);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs_x, off16, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(v2, rs_x, off8, 0, 0);
+            }
+        }
+    };
+    int spin_budget = 1 << 22;
+    int flag_seen = 0;                                                // the band above's progress as last seen (polled ahead of its use)
+    auto wait_prev = [&](int c) {                                     // columns of chunk c of the line above final?
+        if (band == 0 || c > cmax) return;
+        const int need = min(W, (c + 1) * kCW);
+        int f = __builtin_amdgcn_readfirstlane(flag_seen);
+        if (f >= need) return;
+        f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(prog_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        while (f < need && spin_budget > 0) {
+            --spin_budget;
+            __builtin_amdgcn_s_sleep(4);
+            f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(prog_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        if (f < need && lane == 0) a.work[0] = 1;
+    };
+    auto publish = [&](int done_cols) {
+        if (lane == 0) __hip_atomic_store(prog + band, done_cols, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
+    // ---- what a step needs, read from the tile one step ahead ---------------------------------------------------------------
+    // (the b tile has the layout of the x tile, kXSBytes further on: the address of b (y, c) is the address x (y, c) had a step ago)
+    struct In { double own1, down2, b, up; int p; };
+    unsigned own_addr_prev = 0;                                       // LDS address of x (y, c) for the column c read as "own1" a step ago
+    // No conditionals: every address lies inside the ring whatever x is, a value read for a column outside the line (or for a
+    // lane that has not started / has finished) is never used -- the row patterns there have no such slot (no coupling across
+    // line ends: StencilTwin.gs_ok), inactive lanes compute nothing that is kept.
+    auto read_inputs = [&](int x) -> In {                             // for the step that relaxes column x of the lane's line
+        In I;
+        const unsigned c1 = (unsigned)(x + 1);
+        const unsigned s1 = ((c1 >> 4) & (kNCH - 1)) * kSlotBytes, pc1 = (c1 >> 1) & 7u, h1 = (c1 & 1u) * 8u;
+        const unsigned own_addr = s1 + rowoff + pc1 * 16u + h1;
+        I.own1 = ldsd(own_addr);
+        I.down2 = ldsd(own_addr + 128u);
+        I.b = ldsd(own_addr_prev + kXSBytes);
+        own_addr_prev = own_addr;
+        const unsigned sbo = (((unsigned)x >> 4) & (kNCH - 1)) * kSlotBytes;
+        const unsigned o = palign + ((unsigned)x & 15u);
+        I.p = (int)s_tile[sbo + kXSBytes + kBSBytes + (o >> 2) * 256u + (unsigned)lane * 4u + (o & 3u)];
+        I.up = ldsd(sbo + kXSBytes + kBSBytes + kPSBytes + ((unsigned)x & 15u) * 8u);
+        return I;
+    };
+
+    const int hot = a.hot;
+    double hv[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) hv[q] = a.hot_val[q];
+    // a diagonal that is a power of two: t / d == t * (1 / d) bit for bit (both round the same exact number), so the
+    // interior rows skip the division -- ~25 dependent instructions on the critical path of every step
+    const double hrc = a.hot_rcp;
+    const bool hpow2 = hrc != 0.0;
+
+    // prologue: the first kLead chunks (the line above: one chunk less ahead, see below)
+    for (int c = 0; c < kLead; ++c) issue_chunk(c, false);          // (only the line above depends on another band)
+    for (int c = 0; c < kLead - 1; ++c) {
+        wait_prev(c);
+        issue_up(c);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    double U0 = 0.0, U1 = 0.0;                // new values of the line above at columns x-1, x
+    double D0 = 0.0, D1 = 0.0, D2 = 0.0;      // old values of the line below at x-1, x, x+1
+    double O0 = 0.0, O1 = 0.0;                // old values of the own line at x, x+1
+    double R = 0.0;                           // own result of the previous step = new (y, x-1)
+    int flushed = -1;                         // last chunk whose stores have completed and been published
+    int issued_flush = -1;
+    const int T_end = W + last_lane;          // steps: the last line relaxes column W - 1 at step W - 1 + last_lane
+    In nxt = read_inputs(-1 - lane);          // (warm-up of the windows: column x + 1 = 0 for lane 0)
+    // every lane needs old (y, 0) / (y+1, 0) when it starts: the step before its first one reads them (x = -1)
+    for (int t = -1; t < T_end; ++t) {
+        if (t >= 0 && (t & (kCW - 1)) == 0) {
+            // lane 0 enters chunk p: chunk p - 5 is complete and leaves; chunk p + 2 is requested -- and the line above of
+            // chunk p + 1 (one chunk less ahead: what this band waits for is the band above, so it asks as late as it can)
+            const int p = t >> 4;
+            if (p - kFlushLag >= 0 && p - kFlushLag <= cmax) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                flush_chunk(p - kFlushLag);
+                issued_flush = p - kFlushLag;
+            }
+            wait_prev(p + kLead - 1);
+            issue_chunk(p + kLead, false);
+            issue_up(p + kLead - 1);
+        } else if (t >= 0 && (t & (kCW - 1)) == 6) {
+            // six steps later everything requested at the top of the period has landed and the flush stores are done:
+            // publish them (the band below waits for exactly this), and look at the band above now for the next period
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (issued_flush > flushed) {
+                flushed = issued_flush;
+                publish(min(W, (flushed + 1) * kCW));
+            }
+            flag_seen = __hip_atomic_load(prog_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const In cur = nxt;
+        const int x = t - lane;
+        nxt = read_inputs(x + 1);
+        // ---- windows move one column to the right -----------------------------------------------------------------------
+        const double inU = dpp_lower(R);                               // lane l-1's result of the previous step = new (y-1, x)
+        U0 = U1;
+        U1 = (lane == 0) ? cur.up : inU;
+        D0 = D1;
+        D1 = D2;
+        D2 = cur.down2;
+        O0 = O1;
+        O1 = cur.own1;
+        const bool act = line_ok && x >= 0 && x < W;
+        double xn;
+        if (__all(act && cur.p == hot)) {                              // wave-uniform
+            double rsum = 0.0;
+            if ((UM >> 0) & 1u) rsum = rsum + hv[0] * U0;
+            if ((UM >> 1) & 1u) rsum = rsum + hv[1] * U1;
+            if ((UM >> 3) & 1u) rsum = rsum + hv[3] * R;
+            if ((UM >> 5) & 1u) rsum = rsum + hv[5] * O1;
+            if ((UM >> 6) & 1u) rsum = rsum + hv[6] * D0;
+            if ((UM >> 7) & 1u) rsum = rsum + hv[7] * D1;
+            if ((UM >> 8) & 1u) rsum = rsum + hv[8] * D2;
+            xn = hpow2 ? (cur.b - rsum) * hrc : (cur.b - rsum) / hv[4];
+            R = xn;
+        } else {
+            const int pq = act ? cur.p : 0;
+            const int m = act ? s_mask[pq] : 0;
+            double vv[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) vv[q] = ((UM >> q) & 1u) ? s_val[pq * 9 + q] : 0.0;
+            double rsum = 0.0;
+            double t_;
+            if ((UM >> 0) & 1u) { t_ = rsum + vv[0] * U0; rsum = ((m >> 0) & 1) ? t_ : rsum; }
+            if ((UM >> 1) & 1u) { t_ = rsum + vv[1] * U1; rsum = ((m >> 1) & 1) ? t_ : rsum; }
+            if ((UM >> 3) & 1u) { t_ = rsum + vv[3] * R; rsum = ((m >> 3) & 1) ? t_ : rsum; }
+            if ((UM >> 5) & 1u) { t_ = rsum + vv[5] * O1; rsum = ((m >> 5) & 1) ? t_ : rsum; }
+            if ((UM >> 6) & 1u) { t_ = rsum + vv[6] * D0; rsum = ((m >> 6) & 1) ? t_ : rsum; }
+            if ((UM >> 7) & 1u) { t_ = rsum + vv[7] * D1; rsum = ((m >> 7) & 1) ? t_ : rsum; }
+            if ((UM >> 8) & 1u) { t_ = rsum + vv[8] * D2; rsum = ((m >> 8) & 1) ? t_ : rsum; }
+            const double diag = ((m >> 4) & 1) ? vv[4] : 0.0;
+            const double q_ = (cur.b - rsum) / (diag != 0.0 ? diag : 1.0);
+            xn = diag != 0.0 ? q_ : O0;
+            R = act ? xn : R;
+        }
+        if (act) *reinterpret_cast<double *>(s_tile + taddr(rowoff, frow, x)) = xn;     // the new value replaces the old one in the tile
+    }
+    // the chunks still in the ring leave, then everything of this band is done
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    for (int fc = issued_flush + 1; fc <= cmax; ++fc) flush_chunk(fc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    publish(W);
+}
+
+template <unsigned UM>
+int launch_lds(GArgs a, hipStream_t st)
+{
+    hipLaunchKernelGGL((gs_band_lds_kernel<UM>), dim3((unsigned)a.nbands), dim3(64), 0, st, a);
+    LMG_CHECK_LAUNCH();
+    return LMG_OK;
+}
+
 template <unsigned UM>
 int launch(GArgs a, hipStream_t st)
 {
@@ -323,6 +595,7 @@ int launch(GArgs a, hipStream_t st)
 
 int g_gs_max_sweeps = kMaxSweeps;           // sweeps pipelined in one launch (1 = a launch per sweep)
 int g_gs_multi_max_rows = 8000000;          // ... on levels of at most this many rows
+int g_gs_lds = -1;                          // bands staged through LDS (gs_band_lds_kernel): -1 = where one sweep per launch runs anyway, 0 = never, 1 = wherever possible
 
 }  // namespace
 
@@ -338,12 +611,18 @@ int lmg_gsw_tune_set(const char *key, int v)
         g_gs_multi_max_rows = v;
         return LMG_OK;
     }
+    if (strcmp(key, "gsw_lds") == 0) {
+        if (v < -1 || v > 1) return LMG_ERR_ARG;
+        g_gs_lds = v;
+        return LMG_OK;
+    }
     return LMG_ERR_ARG;
 }
 int lmg_gsw_tune_get(const char *key)
 {
     if (strcmp(key, "gsw_max_sweeps") == 0) return g_gs_max_sweeps;
     if (strcmp(key, "gsw_multi_max_rows") == 0) return g_gs_multi_max_rows;
+    if (strcmp(key, "gsw_lds") == 0) return g_gs_lds;
     return LMG_ERR_ARG;
 }
 
@@ -384,9 +663,14 @@ int lmg_stencil_gs_sweep(int64_t n, int32_t line_stride, const uint8_t *pid, int
     a.work = reinterpret_cast<int *>(work);
     a.hot = -1;
     for (int k = 0; k < 9; ++k) a.hot_val[k] = 0.0;
+    a.hot_rcp = 0.0;
     if (hot_pattern >= 0 && hot_pattern < npat && h_hot_val && h_hot_val[4] != 0.0) {
         a.hot = hot_pattern;
         for (int k = 0; k < 9; ++k) a.hot_val[k] = h_hot_val[k];
+        int e = 0;
+        const double mant = frexp(h_hot_val[4], &e);
+        // +-2^k, with 1 / d still a normal number: t / d and t * (1 / d) are the same correctly rounded number
+        if ((mant == 0.5 || mant == -0.5) && e > -1000 && e < 1000) a.hot_rcp = 1.0 / h_hot_val[4];
     }
     hipStream_t st = lmg_stream(stream);
     a.sweeps = 1;
@@ -394,12 +678,23 @@ int lmg_stencil_gs_sweep(int64_t n, int32_t line_stride, const uint8_t *pid, int
         // several sweeps per launch only while the level lives in the Infinity Cache: their loads of x bypass L2 (16 bytes
         // per lane and iteration straight from memory), which costs more than the saved pipeline fills beyond it
         // (3 sweeps: 513^2 1.19 vs 2.43 ms, 1025^2 2.40 vs 4.80, 2049^2 7.2 vs 10.4, 3073^2 15.1 vs 16.0, 4097^2 26.8 vs 22.4)
-        const int per_launch = n <= g_gs_multi_max_rows ? g_gs_max_sweeps : 1;
+        int per_launch = n <= g_gs_multi_max_rows ? g_gs_max_sweeps : 1;
+        // bands staged through LDS: one sweep per launch, operators without the upper-right slot, 16-byte aligned vectors (the
+        // piece that straddles the end of a vector of odd length is then inside its last 16 bytes), at least one full chunk
+        const bool lds_ok = !(union_mask & 4u) && (union_mask == kMask5 || union_mask == kMask7) && line_stride >= 64 &&
+                            lmg_aligned16(x) && lmg_aligned16(b) && (reinterpret_cast<uintptr_t>(pid) & 3u) == 0;
+        const bool use_lds = lds_ok && (g_gs_lds == 1 || (g_gs_lds < 0 && per_launch == 1));
+        if (use_lds) per_launch = 1;
         a.sweeps = sweeps - sw < per_launch ? sweeps - sw : per_launch;
         // ticket and progress counters back to zero (a memset node when captured into a hipGraph)
         // (the error flag at [0] is cleared by the caller once and stays set)
         if (hipMemsetAsync(a.work + 1, 0, 4 * (size_t)(a.sweeps * a.nbands + 2), st) != hipSuccess) return LMG_ERR_LAUNCH;
         int rc;
+        if (use_lds) {
+            rc = union_mask == kMask5 ? launch_lds<kMask5>(a, st) : launch_lds<kMask7>(a, st);
+            if (rc != LMG_OK) return rc;
+            continue;
+        }
         switch (union_mask) {
         case kMask5: rc = launch<kMask5>(a, st); break;
         case kMask9: rc = launch<kMask9>(a, st); break;

@@ -465,7 +465,8 @@ class RowPatterns:
         if uniq is None:
             return None
         npat = int(uniq.numel())
-        pid = torch.empty(n, dtype=torch.uint8, device=dev)
+        # (32 spare bytes behind the ids: the LDS-staged Gauss-Seidel bands fetch them in aligned dwords, up to 19 bytes past n)
+        pid = torch.zeros(n + 32, dtype=torch.uint8, device=dev)[:n]
         PackedCSR._encode_values(hashes.view(F64), uniq, 1, pid)
         del hashes
         rep = torch.full((256,), -1, dtype=I32, device=dev)

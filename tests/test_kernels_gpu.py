@@ -213,6 +213,49 @@ def test_wavefront_gauss_seidel_bit_exact(name):
         ops.set_wavefront_gs_enabled(True)
 
 
+@pytest.mark.parametrize("name", ["poisson2d_300", "seven_point_150", "poisson2d_129", "poisson2d_1100", "ragged_lines_77x203"])
+def test_gauss_seidel_bands_staged_through_lds_bit_exact(name):
+    """gs_band_lds_kernel (the band's lines in 16-column chunks through LDS-DMA, results written back into the tile,
+    coalesced chunk stores; what single sweeps of 5- / 7-point operators run beyond the Infinity Cache) forced on small
+    grids: one band and many, partial last band, line strides that are no multiple of the chunk, a last line shorter
+    than the others -- against pyamg's sweep restated in oracle/lmg_oracle.c, bitwise, and against the register kernel."""
+    if name == "poisson2d_300":
+        A = K.as_csr(P.poisson_2d_structured(299)[0])
+    elif name == "poisson2d_1100":
+        A = K.as_csr(P.poisson_2d_structured(1099)[0])
+    elif name == "seven_point_150":
+        A = _seven_point(149)
+    elif name == "ragged_lines_77x203":
+        # 203 columns, 77 lines minus 5 rows: the last line is short (n no multiple of the line stride)
+        A = K.as_csr(P.poisson_2d_structured(202)[0])[: 77 * 203 - 5][:, : 77 * 203 - 5]
+        A = K.as_csr(sp.csr_matrix(A))
+    else:
+        A = rpat_case(name)
+    n = A.shape[0]
+    dA = ops.DeviceCSR.from_scipy(A, DEV)
+    dA.pack()
+    assert dA.stencil is not None and ops.stencil_gs_available(dA) and not (dA.stencil.umask & 4) and dA.stencil.W >= 64, name
+    rng = np.random.default_rng(43)
+    x0, b = rng.standard_normal(n), rng.standard_normal(n)
+    want = x0.copy()
+    x = dev(x0.copy())
+    db = dev(b)
+    try:
+        ops.tune_set("gsw_lds", 1)
+        for sweeps in (1, 2, 3):
+            K.lib().orc_csr_gs_forward(n, A.indptr, A.indices, A.data, want, b, sweeps)
+            ops.stencil_gs(dA, x, db, sweeps)
+            got = x.cpu().numpy()
+            assert np.array_equal(got, want), (name, sweeps, np.flatnonzero(got != want)[:8], n, dA.stencil.W)
+        ops.stencil_gs_check(dA)
+        ops.tune_set("gsw_lds", 0)
+        x2 = dev(x0.copy())
+        ops.stencil_gs(dA, x2, db, 6)
+        assert torch.equal(x2, x)
+    finally:
+        ops.tune_set("gsw_lds", -1)
+
+
 @pytest.mark.parametrize("m,kind", [(1024, "5pt"), (640, "9pt")])
 def test_wavefront_gauss_seidel_sweeps_pipelined_in_one_launch(m, kind):
     """Several sweeps in ONE launch (band b of sweep s trails band b + 1 of sweep s - 1) against the oracle and against

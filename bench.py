@@ -627,7 +627,27 @@ def main():
             and args.problem == "poisson" and args.transfer == "geometric" and args.size == 4096):
         H = None
         torch.cuda.empty_cache()
+        # the same cfg#4 cycle with the reference's SHIPPED semantics: forward Gauss-Seidel whatever the smoother's name
+        # (Multigrid.py:79-88, :121), exact lexicographic order on the device
+        Hs = Hierarchy(A, hier, dev, coarse_solver=args.coarse)
+        with torch.cuda.stream(Hs.stream):
+            Hs.levels[0].b.copy_(torch.from_numpy(rhs.ravel().copy()).to(dev))
+            gs_graph = Hs.captured_cycle("GaussSeidel", nu, 1.0, "lexicographic")
+            gs_graph.launch()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                gs_graph.launch()
+            torch.cuda.synchronize()
+            t_gs = (time.perf_counter() - t0) / 3
+            Hs.check_smoothers()
+        del Hs, gs_graph
+        torch.cuda.empty_cache()
+        shipped = {"workload": "cfg#4 with the reference's shipped smoother semantics: V(%d,%d), exact forward (lexicographic) "
+                               "Gauss-Seidel on every level, hipGraph replay" % (nu, nu),
+                   "ms_per_cycle": t_gs * 1e3, "DoF_sweeps_per_s": n * (2 * nu + 1) / t_gs, "cycles_timed": 3}
         out["other_configs"] = {
+            "cfg4_as_shipped_forward_gauss_seidel": shipped,
             "cfg3_jittered_7pt_1441x1441_learned_q_5_levels": other_config_leg(
                 "BASELINE cfg#3: P1 Poisson on a jittered triangulation, 1441^2 = 2.08 M DoF, learned-like Q, 5 levels",
                 "jittered", 1440, 5, nu, args.omega, dev),

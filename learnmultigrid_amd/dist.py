@@ -37,10 +37,17 @@ point-to-point xGMI links):
     residual is all-gathered once per cycle and every rank runs the rest of the cycle
     redundantly on its replicated hierarchy, then prolongates from the full coarse
     vector without further communication.
-  * Weighted Jacobi only: row sums are accumulated in the same storage order as on one
+  * Weighted Jacobi: row sums are accumulated in the same storage order as on one
     GPU, so the distributed iterate is bit-identical to the single-GPU one; only the
-    all-reduced norm differs in summation order.  Lexicographic Gauss-Seidel is
-    sequential across the partition and is refused here.
+    all-reduced norm differs in summation order.
+  * Gauss-Seidel -- the smoother the reference ships (Multigrid.py:88, :121) -- as PROCESSOR-BLOCK
+    ("hybrid") Gauss-Seidel: lexicographic order is sequential across the partition, so on a
+    distributed level every rank relaxes ITS rows in lexicographic order with the ghost values of
+    the start of the sweep (one halo exchange per sweep; exact forward sweeps inside the block:
+    the wavefront / level-scheduled kernels on the owned rows).  With one rank it is the
+    reference's sweep; with P ranks it is the standard block variant, and it has its own CPU twin
+    (oracle/vcycle_ref.py HybridGSVCycle) against which it is bit-identical.  The replicated
+    levels below run the exact sweep on every rank.
 
 The class is written against an `ops` object (default: the HIP kernels) so that the
 partition / halo / collective logic is exercised by world_size-2 gloo tests on CPU
@@ -517,19 +524,64 @@ class DistributedVCycle:
             d.x, d.tmp = d.tmp, d.x
         return False
 
+    def _owned_gs_schedule(self, d):
+        """Level schedule of the exact forward sweep over the OWNED rows of a local block (dependencies among owned rows
+        only: ghost columns are constants of the sweep), as local row indices; built once per level."""
+        if getattr(d, "gs_sched", None) is None:
+            import scipy.sparse as sp
+            rp = d.A.rowptr.cpu().numpy().astype(np.int64)
+            ci = d.A.colidx.cpu().numpy().astype(np.int64)
+            lo, hi = d.n_lo, d.n_lo + d.n_own
+            rows = np.repeat(np.arange(d.n_tot, dtype=np.int64), np.diff(rp))
+            keep = (rows >= lo) & (rows < hi) & (ci >= lo) & (ci < hi)
+            pat = sp.csr_matrix((np.ones(int(keep.sum()), dtype=np.int8), (rows[keep] - lo, ci[keep] - lo)),
+                                shape=(d.n_own, d.n_own))
+            pat.sort_indices()
+            sched = self.ops.build_gs_schedule(pat, "lexicographic", self.device)
+            sched.d_rows += lo                                   # local row numbering of the block ([ghosts | owned | ghosts])
+            prep = getattr(self.ops, "gs_prepare", None)
+            if prep is not None:
+                prep(d.A, sched)
+            d.gs_sched = sched
+        return d.gs_sched
+
+    def _smooth_gs(self, d, steps, x_is_zero):
+        """`steps` processor-block Gauss-Seidel sweeps: exchange the ghosts of x, then an exact forward sweep over the
+        owned rows with those ghost values (Multigrid.py:88 inside the block)."""
+        o = self.ops
+        if x_is_zero:
+            o.zero(d.x)
+        wave = getattr(o, "stencil_gs_available", None)
+        # the wavefront kernel relaxes EVERY row of the matrix it is given: only with the classic one-layer halo are the
+        # ghost rows of the local operator empty (and therefore left alone)
+        use_wave = wave is not None and self.halo_depth == 1 and wave(d.A)
+        for k in range(steps):
+            if not (x_is_zero and k == 0):
+                self.exchange(d, d.x)                           # (a zero iterate has zero ghosts)
+            if use_wave:
+                o.stencil_gs(d.A, d.x, d.b, 1)
+            else:
+                o.csr_gs_schedule(d.A, d.x, d.b, self._owned_gs_schedule(d), 1)
+
     def cycle(self, smoother, steps, omega=1.0, l=0, x_is_zero=False):
         """One V-cycle from level l down.  Returns the number of ghost layers on which this level's
         iterate is exact afterwards (what the caller may prolongate from without a message)."""
-        if smoother != "Jacobi":
-            raise ValueError("the distributed V-cycle supports the Jacobi smoother only "
-                             "(lexicographic Gauss-Seidel is sequential across ranks)")
+        if smoother not in ("Jacobi", "GaussSeidel"):
+            raise ValueError("the distributed V-cycle supports the smoothers 'Jacobi' and 'GaussSeidel' "
+                             "(processor-block Gauss-Seidel), not %r" % (smoother,))
+        gs = smoother == "GaussSeidel"
         o = self.ops
         d = self.dl[l]
         D = self.halo_depth
         # nu sweeps + the residual on the ghost layers the restriction reads consume nu + 1 + r_need
-        # layers of one exchange; otherwise (deeper cycles, wide transfers) exchange before every use
-        deep = steps >= 1 and steps + 1 + max(1, self.r_need[l]) <= D
-        have_r = self._smooth(d, steps, omega, x_is_zero, deep, want_residual=True)
+        # layers of one exchange; otherwise (deeper cycles, wide transfers) exchange before every use.
+        # Block Gauss-Seidel relaxes owned rows only: the ghost layers are never brought forward, every use exchanges.
+        deep = (not gs) and steps >= 1 and steps + 1 + max(1, self.r_need[l]) <= D
+        if gs:
+            self._smooth_gs(d, steps, x_is_zero)
+            have_r = False
+        else:
+            have_r = self._smooth(d, steps, omega, x_is_zero, deep, want_residual=True)
         if not deep:
             self.exchange(d, d.x)
         if not have_r:
@@ -566,6 +618,9 @@ class DistributedVCycle:
             o.csr_spmv(d.P, fl.x, d.x, 1.0, 1.0)      # the replicated correction is complete on every rank
             V = D - steps if want_local else 0
         local_up = want_local and V >= steps
+        if gs:
+            self._smooth_gs(d, steps, False)
+            return 0
         self._smooth(d, steps, omega, False, deep, exchanged=local_up)
         return V - steps if local_up else 0
 
@@ -585,6 +640,9 @@ class DistributedVCycle:
         key = (smoother, steps, omega, l)
         g = self._tail_graphs.get(key)
         if g is None:
+            prep = getattr(self.full, "prepare_smoother", None)
+            if prep is not None:
+                prep(smoother, "lexicographic", l)               # (device -> host reads, allocations: not inside a capture)
             before = [(lev.x, lev.tmp) for lev in self.full.levels]
             g = self.ops.CapturedGraph()
             with g:

@@ -356,18 +356,24 @@ class Hierarchy:
         for lev in self.levels[:-1]:
             chk(lev.A)
 
+    def prepare_smoother(self, smoother, gs_mode="lexicographic", l_from=0):
+        """Everything a Gauss-Seidel cycle would otherwise do lazily on its first sweep -- the wavefront kernel's eligibility
+        test (a device -> host read) and work buffer, the level schedules -- from level l_from down: nothing of it may happen
+        while a hipGraph is being captured."""
+        if smoother != "GaussSeidel":
+            return
+        for l in range(l_from, len(self.levels) - 1):
+            if self._wavefront_gs(l, gs_mode):
+                self.ops.stencil_gs(self.levels[l].A, self.levels[l].tmp, self.levels[l].b, 0)
+            else:
+                self.gs_schedule(l, gs_mode)
+
     def captured_cycle(self, smoother, steps, omega, gs_mode):
         """The same launch sequence as cycle(), captured once into a hipGraph and replayed."""
         key = (smoother, steps, omega, gs_mode)
         g = self._graphs.get(key)
         if g is None:
-            if smoother == "GaussSeidel":
-                for l in range(len(self.levels) - 1):
-                    if self._wavefront_gs(l, gs_mode):
-                        # allocate the kernel's work buffer now: nothing may be allocated during capture
-                        self.ops.stencil_gs(self.levels[l].A, self.levels[l].tmp, self.levels[l].b, 0)
-                    else:
-                        self.gs_schedule(l, gs_mode)            # host work must not happen in capture
+            self.prepare_smoother(smoother, gs_mode)
             before = [(lev.x, lev.tmp) for lev in self.levels]
             g = self.ops.CapturedGraph()
             with g:

@@ -171,5 +171,22 @@ class SpGEMMPlan:
         return new
 
 
-def build_gs_schedule(*a, **k):
-    raise NotImplementedError("Gauss-Seidel schedules are exercised by the GPU tests")
+class _Sched:
+    def __init__(self, rows):
+        self.d_rows = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32))
+
+
+def build_gs_schedule(A_scipy_csr, kind, device):
+    """The CPU stand-in executes a lexicographic schedule as what it is: the rows in ascending order."""
+    if kind != "lexicographic":
+        raise NotImplementedError(kind)
+    return _Sched(np.arange(A_scipy_csr.shape[0], dtype=np.int32))
+
+
+def csr_gs_schedule(A, x, b, sched, sweeps=1):
+    n, rp, ci, va = _raw(A)
+    xx = np.ascontiguousarray(_np(x))
+    rows = np.sort(_np(sched.d_rows)).astype(np.int32)
+    for _ in range(int(sweeps)):
+        K.lib().orc_csr_gs_rows(rp, ci, va, xx, np.ascontiguousarray(_np(b)), rows, rows.size)
+    _np(x)[:] = xx

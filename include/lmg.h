@@ -470,6 +470,16 @@ int lmg_coarse_back_gather(int64_t nblocks, int64_t rows, int64_t cols, const do
                            const int32_t *d_xidx, const double *d_z, int64_t z_stride, double alpha, const int32_t *d_oidx,
                            double *d_out, int accumulate, int64_t ntail, const int32_t *d_tail_idx, void *stream);
 
+/* Dense fp64 helpers of the coarse-solver SETUP (csrc/gemm.hip; what NumPy / SuperLU do on the host inside the reference's
+ * per-cycle `spsolve`, Multigrid.py:106, is a one-off factorisation here): row-major, leading dimensions, batch strides.
+ *   lmg_batched_gemm: C[b] = alpha * A[b] (M x K) * B[b] (K x N) + beta * C[b]   (beta == 0: C is not read)
+ *   lmg_copy2d      : dst[b][r][c] = alpha * src[b][r][c]   (accumulate != 0: += ) */
+int lmg_batched_gemm(int64_t batch, int64_t M, int64_t N, int64_t K, double alpha, const double *d_A, int64_t lda,
+                     int64_t stride_a, const double *d_B, int64_t ldb, int64_t stride_b, double beta, double *d_C,
+                     int64_t ldc, int64_t stride_c, void *stream);
+int lmg_copy2d(int64_t batch, int64_t rows, int64_t cols, double alpha, const double *d_src, int64_t ld_src,
+               int64_t stride_src, double *d_dst, int64_t ld_dst, int64_t stride_dst, int accumulate, void *stream);
+
 /* Setup helper: d_counts[((y & 1) * 2 + (x & 1)) * 256 + id] += number of rows i = y * line_stride + x with pattern id
  * d_pid[i] = id (d_counts: 1024 int32, zeroed by the caller). */
 int lmg_pattern_parity_counts(int64_t n, int32_t line_stride, const uint8_t *d_pid, int32_t *d_counts, void *stream);

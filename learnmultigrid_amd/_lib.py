@@ -97,6 +97,8 @@ SIGNATURES = {
     "lmg_coarse_back": (_c.c_int, [_i64, _i64, _i64, _p, _p, _p, _p, _i64, _f64, _p, _p, _c.c_int, _i64, _p]),
     "lmg_coarse_front_gather": (_c.c_int, [_i64, _i64, _p, _p, _p, _p, _i64, _p, _p, _p]),
     "lmg_coarse_back_gather": (_c.c_int, [_i64, _i64, _i64, _p, _p, _p, _p, _i64, _f64, _p, _p, _c.c_int, _i64, _p, _p]),
+    "lmg_batched_gemm": (_c.c_int, [_i64, _i64, _i64, _i64, _f64, _p, _i64, _i64, _p, _i64, _i64, _f64, _p, _i64, _i64, _p]),
+    "lmg_copy2d": (_c.c_int, [_i64, _i64, _i64, _f64, _p, _i64, _i64, _p, _i64, _i64, _c.c_int, _p]),
     "lmg_pattern_parity_counts": (_c.c_int, [_i64, _i32, _p, _p, _p]),
     "lmg_block_copy": (_c.c_int, [_i64, _i64, _p, _i64, _p, _i64, _p]),
     "lmg_csr_to_dense": (_c.c_int, [_i64, _i64, _p, _p, _p, _p, _p]),

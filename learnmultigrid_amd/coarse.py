@@ -52,18 +52,12 @@ BACKSUB_ONE_LAUNCH = True     # banded solver: x_I = y_I - (A_II^-1 A_IS) x_S in
 
 def _inv_schur(A, leaf=_INV_LEAF):
     """Recursive 2x2 Schur-complement inversion of A (..., n, n): only small (batched) leaf
-    inversions and plain rocBLAS GEMMs (torch.matmul).  No pivoting across blocks; the callers
-    verify the result (dense_inverse)."""
+    inversions and plain GEMMs.  No pivoting across blocks; the callers verify the result (dense_inverse)."""
+    if A.is_cuda:
+        A3 = A if A.dim() == 3 else A.unsqueeze(0)
+        return _inv_schur_dev(A3.contiguous(), 128).reshape(A.shape)
     n = A.shape[-1]
     if n <= leaf:
-        if A.is_cuda and n <= 128:
-            # own batched Gauss-Jordan kernel: no rocSOLVER (thousands of small panel launches, and 0.4 s to
-            # load the library in a fresh process)
-            from . import ops as _ops
-            M = _ops.batched_inverse(A.reshape(-1, n, n))
-            if M is None:
-                raise RuntimeError("singular leaf")
-            return M.reshape(A.shape)
         return torch.linalg.inv(A)
     h = n // 2
     A11, A12, A21, A22 = A[..., :h, :h], A[..., :h, h:], A[..., h:, :h], A[..., h:, h:]
@@ -79,20 +73,72 @@ def _inv_schur(A, leaf=_INV_LEAF):
     return out
 
 
+def _inv_schur_dev(A, leaf):
+    """The same recursion on a device batch (b, n, n) with the library's own kernels only: batched Gauss-Jordan leaves
+    (lmg_batched_inverse), lmg_batched_gemm / lmg_copy2d on strided sub-block views -- no rocBLAS, no rocSOLVER, no library
+    elementwise kernels (each costs 50 - 200 ms of code-object loading the first time a process uses it)."""
+    from . import ops as _ops
+    b, n, _ = A.shape
+    dev = A.device
+    if n <= leaf:
+        M = _ops.batched_inverse(A)
+        if M is None:
+            raise RuntimeError("singular leaf")
+        return M
+    h = n // 2
+    new = lambda r, c: torch.empty((b, r, c), dtype=F64, device=dev)
+    A11, A12, A21, A22 = A[:, :h, :h], A[:, :h, h:], A[:, h:, :h], A[:, h:, h:]
+    I11 = _inv_schur_dev(_ops.copy2d(A11, new(h, h)), leaf)
+    T = _ops.gemm(I11, A12, new(h, n - h))
+    S = _ops.copy2d(A22, new(n - h, n - h))
+    _ops.gemm(A21, T, S, alpha=-1.0, beta=1.0)                        # S = A22 - A21 A11^-1 A12
+    IS = _inv_schur_dev(S, leaf)
+    out = new(n, n)
+    _ops.copy2d(IS, out[:, h:, h:])
+    V = _ops.gemm(A21, I11, new(n - h, h))
+    _ops.gemm(IS, V, out[:, h:, :h], alpha=-1.0)                      # -W,  W = S^-1 A21 A11^-1
+    _ops.gemm(T, IS, out[:, :h, h:], alpha=-1.0)
+    _ops.copy2d(I11, out[:, :h, :h])
+    _ops.gemm(T, out[:, h:, :h], out[:, :h, :h], alpha=-1.0, beta=1.0)    # A11^-1 + T W
+    return out
+
+
+def _defect_dev(dense, M):
+    """|| I - A M ||_F of a device batch (>= the largest entry of the defect), own kernels only."""
+    from . import ops as _ops
+    d3 = dense if dense.dim() == 3 else dense.unsqueeze(0)
+    m3 = M if M.dim() == 3 else M.unsqueeze(0)
+    b, n, _ = d3.shape
+    D = torch.zeros((b, n, n), dtype=F64, device=dense.device)
+    ones = torch.ones((b, n, 1), dtype=F64, device=dense.device)
+    _ops.copy2d(ones, torch.as_strided(D, (b, n, 1), (n * n, n + 1, 1)))       # the diagonal as a strided column
+    _ops.gemm(d3, m3, D, alpha=-1.0, beta=1.0)
+    flat = D.reshape(-1)
+    part = torch.empty(_ops.partials_count(flat.numel()), dtype=F64, device=dense.device)
+    out = torch.zeros(1, dtype=F64, device=dense.device)
+    _ops.dot(flat, flat, part, out)
+    v = float(out.item())
+    return float("inf") if v != v else v ** 0.5
+
+
 def dense_inverse(dense, polish=2, tol=1e-9):
     """A^-1 on the device (SETUP phase) for one matrix (n, n) or a batch (k, n, n).
-    1. block Schur recursion on GEMMs with small pivoted leaf inversions (measured on MI355X:
-       25 strips of 540^2 in 3.9 ms, 3141^2 in 16 ms; rocSOLVER's getrf/getri path takes 51 /
-       30 ms and cannot get its trsm workspace at all for n ~ 16 000 on this stack);
-    2. if max|I - A M| >= tol (a pivot the recursion could not see): torch.linalg.inv, then
+    1. block Schur recursion on GEMMs with small pivoted leaf inversions (own kernels on the device: see
+       _inv_schur_dev);
+    2. if the defect I - A M is not below tol (a pivot the recursion could not see): torch.linalg.inv, then
        `polish` Newton-Schulz steps M <- M (2I - A M);
     3. as a last resort a pure Newton-Schulz iteration from A^T/(|A|_1 |A|_inf), which converges
        for every nonsingular A.
     Raises if the operator is numerically singular."""
     n = dense.shape[-1]
-    eye = torch.eye(n, dtype=F64, device=dense.device)
+    eye = None
 
     def defect(M):
+        nonlocal eye
+        if dense.is_cuda:
+            return _defect_dev(dense, M)
+        if eye is None:
+            eye = torch.eye(n, dtype=F64, device=dense.device)
         return float((eye - dense @ M).abs().max())
 
     def good(M):
@@ -105,13 +151,14 @@ def dense_inverse(dense, polish=2, tol=1e-9):
         M = None
     if good(M):
         return M.contiguous()
+    eye = torch.eye(n, dtype=F64, device=dense.device)
     try:
         M = torch.linalg.inv(dense)
     except RuntimeError:
         M = None
     if M is not None and bool(torch.isfinite(M).all()):
         for _ in range(polish):
-            if defect(M) < 1e-13:
+            if float((eye - dense @ M).abs().max()) < 1e-13:
                 break
             M = M @ (2.0 * eye - dense @ M)
         if good(M):
@@ -120,7 +167,7 @@ def dense_inverse(dense, polish=2, tol=1e-9):
     M = dense.transpose(-1, -2).contiguous() / nrm
     for _ in range(200):
         M = M @ (2.0 * eye - dense @ M)
-        if defect(M) < 1e-12:
+        if float((eye - dense @ M).abs().max()) < 1e-12:
             break
     if not good(M):
         raise ValueError("coarsest operator is numerically singular (cannot be inverted)")
@@ -569,8 +616,12 @@ class GridBlockSolver:
         self.blocks = dense_inverse(dense.view(k, s, s))
         ais = self._place(v, self._src_IS, self._dst_IS, k * s * cwp)
         asi = self._place(v, self._src_SI, self._dst_SI, k * cwp * s)
-        self.Wm = torch.bmm(self.blocks, ais.view(k, s, cwp)).contiguous()               # k x s x cwp: A_II^-1 A_IS
-        upd = torch.bmm(asi.view(k, cwp, s), self.Wm).reshape(-1)                        # k x cwp x cwp
+        if v.is_cuda and hasattr(self.ops, "gemm"):
+            self.Wm = self.ops.gemm(self.blocks, ais.view(k, s, cwp), torch.empty((k, s, cwp), dtype=F64, device=dev))
+            upd = self.ops.gemm(asi.view(k, cwp, s), self.Wm, torch.empty((k, cwp, cwp), dtype=F64, device=dev)).reshape(-1)
+        else:
+            self.Wm = torch.bmm(self.blocks, ais.view(k, s, cwp)).contiguous()           # k x s x cwp: A_II^-1 A_IS
+            upd = torch.bmm(asi.view(k, cwp, s), self.Wm).reshape(-1)                    # k x cwp x cwp
         Sc = self._place(v, self._src_SS, self._dst_SS, nS * nS)
         for sel, dst in self._upd:                       # S[dst] -= upd[sel], every destination once per pass
             tmp = torch.empty(sel.numel(), dtype=F64, device=dev)

@@ -1380,6 +1380,42 @@ def coarse_back_gather(W, x_tail, xidx, z, alpha, oidx, tail_idx, out, accumulat
           "lmg_coarse_back_gather")
 
 
+def _mat_view(t):
+    """(batch, rows, cols, ld, batch stride, data pointer) of a 2-D / 3-D float64 device tensor whose rows are contiguous
+    (any leading dimension, any batch stride: sub-blocks of larger matrices)."""
+    if t.dtype != F64 or not t.is_cuda or t.dim() not in (2, 3) or t.stride(-1) != 1 and t.shape[-1] > 1:
+        raise TypeError("expected a float64 device matrix with contiguous rows")
+    if t.dim() == 2:
+        return 1, t.shape[0], t.shape[1], max(t.stride(0), t.shape[1]), 0, t.data_ptr()
+    return t.shape[0], t.shape[1], t.shape[2], max(t.stride(1), t.shape[2]), t.stride(0), t.data_ptr()
+
+
+def gemm(A, B, C, alpha=1.0, beta=0.0):
+    """C = alpha * A @ B + beta * C on (batches of) strided matrix views (lmg_batched_gemm): the coarse-solver setup's
+    products without a BLAS library (whose first use costs more than the setup itself in a fresh process)."""
+    ba, M, K, lda, sa, pa = _mat_view(A)
+    bb, K2, N, ldb, sb, pb = _mat_view(B)
+    bc, M2, N2, ldc, sc, pc = _mat_view(C)
+    if K != K2 or M != M2 or N != N2 or len({ba, bb, bc} - {1}) > 1:
+        raise ValueError("gemm: shapes %s @ %s -> %s" % (tuple(A.shape), tuple(B.shape), tuple(C.shape)))
+    batch = max(ba, bb, bc)
+    if bc != batch:
+        raise ValueError("gemm: the result needs the batch dimension")
+    check(_lib.lib().lmg_batched_gemm(batch, M, N, K, float(alpha), pa, lda, sa if ba > 1 else 0, pb, ldb, sb if bb > 1 else 0,
+                                      float(beta), pc, ldc, sc, _s(C)), "lmg_batched_gemm")
+    return C
+
+
+def copy2d(src, dst, alpha=1.0, accumulate=False):
+    """dst (+)= alpha * src on (batches of) strided matrix views of equal shape (lmg_copy2d)."""
+    bs, R, Cc, lds, ss, ps = _mat_view(src)
+    bd, R2, C2, ldd, sd, pd = _mat_view(dst)
+    if (bs, R, Cc) != (bd, R2, C2):
+        raise ValueError("copy2d: shapes %s -> %s" % (tuple(src.shape), tuple(dst.shape)))
+    check(_lib.lib().lmg_copy2d(bs, R, Cc, float(alpha), ps, lds, ss, pd, ldd, sd, 1 if accumulate else 0, _s(dst)), "lmg_copy2d")
+    return dst
+
+
 def csr_to_dense(A, dense):
     check(_lib.lib().lmg_csr_to_dense(A.shape[0], A.shape[1], _p(A.rowptr), _p(A.colidx), _p(A.vals), _p(dense), _s(A.rowptr)),
           "lmg_csr_to_dense")

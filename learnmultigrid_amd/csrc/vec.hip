@@ -337,44 +337,54 @@ __global__ void __launch_bounds__(kBlock) coarse_back_kernel(int64_t nb, int64_t
 //   front: y[k*bs + r] = sum_c M_k[r][c] * b[idx[k*bs + c]]  (idx < 0: padding, contributes 0),  tail_out[i] = b[tail_idx[i]]
 //   back : out[oidx[k*rows + r]] (+)= z[k*zs + r] + alpha * sum_c M_k[r][c] * x[xidx[k*cols + c]]  (oidx < 0: padding row),
 //          out[tail_idx[i]] (+)= x[i]
-// One wave per row, all loads of a row issued before its sums (rows are a few hundred entries at most), fixed order.
-__global__ void __launch_bounds__(kBlock) coarse_front_gather_kernel(int64_t n, int64_t bs, const double *M, const double *b,
+// (fixed order of additions: lane sums over 128-entry passes, butterfly over the wave)
+constexpr int kCoarseRows = 36;       // rows of a block per workgroup: 9 per wave, all their loads in flight at once
+
+// One workgroup = kCoarseRows rows of ONE block: the block's operand segment (its gathered right-hand side / separator
+// window) is gathered ONCE into LDS, then every wave walks its rows with all loads of all its rows issued before the first
+// sum (rows are 50 - 300 entries: a wave per row with a grid-stride loop spent its time in three dependent round trips).
+__global__ void __launch_bounds__(kBlock) coarse_front_gather_kernel(int64_t nblocks, int64_t bs, const double *M, const double *b,
                                                                      const int *idx, double *y, int64_t ntail,
                                                                      const int *tail_idx, double *tail_out)
 {
-    const int lane = threadIdx.x & (LMG_WAVE - 1);
-    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LMG_WAVE;
-    const int64_t nwaves = (int64_t)gridDim.x * kBlock / LMG_WAVE;
-    for (int64_t row = wave; row < n; row += nwaves) {
-        const double2 *M2 = reinterpret_cast<const double2 *>(M + row * bs);
-        const int2 *i2 = reinterpret_cast<const int2 *>(idx + (row / bs) * bs);
-        double s = 0.0;
-        constexpr int CH = 4;
-        for (int64_t j0 = lane; j0 < bs / 2; j0 += (int64_t)CH * LMG_WAVE) {
-            double2 mv[CH];
-            double xa[CH], xb[CH];
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const int64_t j = j0 + (int64_t)c * LMG_WAVE;
-                const int64_t jj = j < bs / 2 ? j : 0;
-                mv[c] = M2[jj];
-                const int2 g = i2[jj];
-                xa[c] = g.x >= 0 ? b[g.x] : 0.0;
-                xb[c] = g.y >= 0 ? b[g.y] : 0.0;
-            }
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                if (j0 + (int64_t)c * LMG_WAVE < bs / 2) {
-                    s += mv[c].x * xa[c];
-                    s += mv[c].y * xb[c];
-                }
-            }
-        }
-        s = lmg_wave_sum(s);
-        if (lane == 0) y[row] = s;
+    extern __shared__ double s_seg[];                              // bs doubles
+    const int t = threadIdx.x, lane = t & (LMG_WAVE - 1), w = t / LMG_WAVE;
+    const int64_t k = blockIdx.x, r0 = (int64_t)blockIdx.y * kCoarseRows;
+    for (int64_t c = t; c < bs; c += kBlock) {
+        const int g = idx[k * bs + c];
+        s_seg[c] = g >= 0 ? b[g] : 0.0;
     }
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ntail; i += (int64_t)gridDim.x * kBlock)
-        tail_out[i] = b[tail_idx[i]];
+    __syncthreads();
+    const double2 *x2 = reinterpret_cast<const double2 *>(s_seg);
+    constexpr int RPW = kCoarseRows / (kBlock / LMG_WAVE);         // 9 rows per wave
+    const int64_t half = bs / 2;
+    double tot[RPW];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) tot[q] = 0.0;
+    for (int64_t j0 = 0; j0 < half; j0 += LMG_WAVE) {              // (rows longer than 128 entries: another pass)
+        const int64_t j = j0 + lane;
+        double2 mv[RPW];
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            const int64_t r = r0 + w + 4 * q;
+            mv[q] = (r < bs && j < half) ? reinterpret_cast<const double2 *>(M + (k * bs + r) * bs)[j] : double2{0.0, 0.0};
+        }
+        const double2 xv = j < half ? x2[j] : double2{0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            double sacc = 0.0;
+            sacc += mv[q].x * xv.x;
+            sacc += mv[q].y * xv.y;
+            tot[q] += lmg_wave_sum(sacc);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int64_t r = r0 + w + 4 * q;
+        if (lane == 0 && r < bs) y[k * bs + r] = tot[q];
+    }
+    if (blockIdx.y == 0)
+        for (int64_t i = k * kBlock + t; i < ntail; i += nblocks * kBlock) tail_out[i] = b[tail_idx[i]];
 }
 
 __global__ void __launch_bounds__(kBlock) coarse_back_gather_kernel(int64_t nb, int64_t rows, int64_t cols, const double *M,
@@ -382,47 +392,50 @@ __global__ void __launch_bounds__(kBlock) coarse_back_gather_kernel(int64_t nb, 
                                                                     int64_t zs, double alpha, const int *oidx, double *out,
                                                                     int accumulate, int64_t ntail, const int *tail_idx)
 {
-    const int lane = threadIdx.x & (LMG_WAVE - 1);
-    const int64_t wave = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / LMG_WAVE;
-    const int64_t nwaves = (int64_t)gridDim.x * kBlock / LMG_WAVE;
-    for (int64_t row = wave; row < nb * rows; row += nwaves) {
-        const int64_t k = row / rows, r = row - k * rows;
-        const int d = oidx[row];
-        if (d < 0) continue;                                     // padding row of the block (wave-uniform)
-        const double2 *M2 = reinterpret_cast<const double2 *>(M + row * cols);
-        const int2 *i2 = reinterpret_cast<const int2 *>(xidx + k * cols);
-        double s = 0.0;
-        constexpr int CH = 2;
-        for (int64_t j0 = lane; j0 < cols / 2; j0 += (int64_t)CH * LMG_WAVE) {
-            double2 mv[CH];
-            double xa[CH], xb[CH];
+    extern __shared__ double s_seg[];                              // cols doubles
+    const int t = threadIdx.x, lane = t & (LMG_WAVE - 1), w = t / LMG_WAVE;
+    const int64_t k = blockIdx.x, r0 = (int64_t)blockIdx.y * kCoarseRows;
+    for (int64_t c = t; c < cols; c += kBlock) s_seg[c] = x[xidx[k * cols + c]];
+    __syncthreads();
+    const double2 *x2 = reinterpret_cast<const double2 *>(s_seg);
+    constexpr int RPW = kCoarseRows / (kBlock / LMG_WAVE);
+    const int64_t half = cols / 2;
+    double tot[RPW];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const int64_t j = j0 + (int64_t)c * LMG_WAVE;
-                const int64_t jj = j < cols / 2 ? j : 0;
-                mv[c] = M2[jj];
-                const int2 g = i2[jj];
-                xa[c] = x[g.x];
-                xb[c] = x[g.y];
-            }
+    for (int q = 0; q < RPW; ++q) tot[q] = 0.0;
+    for (int64_t j0 = 0; j0 < half; j0 += LMG_WAVE) {
+        const int64_t j = j0 + lane;
+        double2 mv[RPW];
 #pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                if (j0 + (int64_t)c * LMG_WAVE < cols / 2) {
-                    s += mv[c].x * xa[c];
-                    s += mv[c].y * xb[c];
-                }
-            }
+        for (int q = 0; q < RPW; ++q) {
+            const int64_t r = r0 + w + 4 * q;
+            mv[q] = (r < rows && j < half) ? reinterpret_cast<const double2 *>(M + (k * rows + r) * cols)[j] : double2{0.0, 0.0};
         }
-        s = lmg_wave_sum(s);
-        if (lane == 0) {
-            const double v = z0[k * zs + r] + alpha * s;
-            out[d] = accumulate ? v + out[d] : v;
+        const double2 xv = j < half ? x2[j] : double2{0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < RPW; ++q) {
+            double sacc = 0.0;
+            sacc += mv[q].x * xv.x;
+            sacc += mv[q].y * xv.y;
+            tot[q] += lmg_wave_sum(sacc);
         }
     }
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < ntail; i += (int64_t)gridDim.x * kBlock) {
-        const int d = tail_idx[i];
-        out[d] = accumulate ? x[i] + out[d] : x[i];
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int64_t r = r0 + w + 4 * q;
+        if (lane == 0 && r < rows) {
+            const int d = oidx[k * rows + r];
+            if (d >= 0) {
+                const double v = z0[k * zs + r] + alpha * tot[q];
+                out[d] = accumulate ? v + out[d] : v;
+            }
+        }
     }
+    if (blockIdx.y == 0)
+        for (int64_t i = k * kBlock + t; i < ntail; i += nb * kBlock) {
+            const int d = tail_idx[i];
+            out[d] = accumulate ? x[i] + out[d] : x[i];
+        }
 }
 
 // How often every pattern id occurs on (even / odd line) x (even / odd column) of a grid with line stride W:
@@ -843,8 +856,9 @@ int lmg_coarse_front_gather(int64_t nblocks, int64_t bs, const double *M, const 
         return LMG_ERR_ARG;
     if (nblocks * bs == 0 && ntail == 0) return LMG_OK;
     if (!lmg_aligned16(M) || (bs % 2) || (reinterpret_cast<uintptr_t>(idx) & 7u)) return LMG_ERR_ALIGN;
-    hipLaunchKernelGGL(coarse_front_gather_kernel, dim3(grid_for(nblocks * bs > 0 ? nblocks * bs : 1, kBlock / LMG_WAVE)),
-                       dim3(kBlock), 0, lmg_stream(stream), nblocks * bs, bs, M, b, idx, y, ntail, tail_idx, tail_out);
+    if (nblocks == 0 || bs == 0 || bs * 8 > 60000 || nblocks > 0x7fffffff) return LMG_ERR_CAPACITY;
+    hipLaunchKernelGGL(coarse_front_gather_kernel, dim3((unsigned)nblocks, (unsigned)((bs + kCoarseRows - 1) / kCoarseRows)),
+                       dim3(kBlock), (size_t)bs * 8, lmg_stream(stream), nblocks, bs, M, b, idx, y, ntail, tail_idx, tail_out);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }
@@ -857,9 +871,10 @@ int lmg_coarse_back_gather(int64_t nblocks, int64_t rows, int64_t cols, const do
     if (nblocks * rows == 0 && ntail == 0) return LMG_OK;
     if (!M || !x || !xidx || !z || !oidx || !out || (ntail > 0 && !tail_idx) || x == out || z == out) return LMG_ERR_ARG;
     if (!lmg_aligned16(M) || (cols % 2) || (reinterpret_cast<uintptr_t>(xidx) & 7u)) return LMG_ERR_ALIGN;
-    hipLaunchKernelGGL(coarse_back_gather_kernel, dim3(grid_for(nblocks * rows > 0 ? nblocks * rows : 1, kBlock / LMG_WAVE)),
-                       dim3(kBlock), 0, lmg_stream(stream), nblocks, rows, cols, M, x, xidx, z, z_stride, alpha, oidx, out,
-                       accumulate, ntail, tail_idx);
+    if (nblocks == 0 || rows == 0 || cols * 8 > 60000 || nblocks > 0x7fffffff) return LMG_ERR_CAPACITY;
+    hipLaunchKernelGGL(coarse_back_gather_kernel, dim3((unsigned)nblocks, (unsigned)((rows + kCoarseRows - 1) / kCoarseRows)),
+                       dim3(kBlock), (size_t)cols * 8, lmg_stream(stream), nblocks, rows, cols, M, x, xidx, z, z_stride, alpha, oidx,
+                       out, accumulate, ntail, tail_idx);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }

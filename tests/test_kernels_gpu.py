@@ -1116,19 +1116,30 @@ def test_row_pattern_sweeps_bit_exact(name, variant, nt):
 
 
 @pytest.mark.parametrize("name", ["poisson2d_129", "poisson1d", "galerkin_9pt", "with_empty_and_diagless_rows",
-                                  "poisson2d_300"])
+                                  "poisson2d_300", "poisson2d_601", "poisson2d_602", "galerkin_9pt_515"])
 @pytest.mark.parametrize("seg_lines,pf", [(0, 0), (4, 2), (7, 2), (1000, 2), ("tile", 16), ("tile", 32)])
 def test_fused_stencil_smoothing_equals_separate_sweeps(name, seg_lines, pf):
     """lmg_stencil_smooth (S sweeps [+ residual] in one pass, iterates in registers) and lmg_stencil_smooth_tiled
     (the same with the iterates in LDS, what small levels run) against the oracle's separate Jacobi sweeps and
     residual, bitwise, for S = 1..3, zero / non-zero initial iterate, with and without the residual, few and many
     line segments per strip / 16- and 32-line tiles."""
-    A = K.as_csr(P.poisson_2d_structured(299)[0]) if name == "poisson2d_300" else rpat_case(name)
+    # (line strides from 512 on run the four-elements-per-lane march: 601 = 1, 602 = 2, 515 = 3 mod 4)
+    if name == "poisson2d_300":
+        A = K.as_csr(P.poisson_2d_structured(299)[0])
+    elif name in ("poisson2d_601", "poisson2d_602"):
+        A = K.as_csr(P.poisson_2d_structured(int(name[-3:]) - 1)[0])
+    elif name == "galerkin_9pt_515":
+        Pf = P.tensor_interpolator_2d(1029)
+        A = K.as_csr(sp.csr_matrix(Pf.T @ P.poisson_2d_structured(1028)[0] @ Pf))
+    else:
+        A = rpat_case(name)
     n = A.shape[0]
     dA = ops.DeviceCSR.from_scipy(A, DEV)
     dA.pack()
     assert dA.stencil is not None
     tiled = seg_lines == "tile"
+    if tiled and n > 200000:
+        pytest.skip("the tiled pass is covered by the smaller cases")
     if tiled and not ops._lib.lib().lmg_stencil_smooth_tiled_supported(dA.stencil.umask):
         pytest.skip("1-D chains run the register kernel")
     rng = np.random.default_rng(77)
@@ -1169,7 +1180,8 @@ def test_fused_stencil_smoothing_equals_separate_sweeps(name, seg_lines, pf):
         ops.TILED_MIN_ROWS = min_tiled
 
 
-@pytest.mark.parametrize("m,kind", [(32, "5pt"), (64, "5pt"), (150, "5pt"), (64, "9pt"), (129, "9pt")])
+@pytest.mark.parametrize("m,kind", [(32, "5pt"), (64, "5pt"), (150, "5pt"), (64, "9pt"), (129, "9pt"), (300, "5pt"), (301, "5pt"),
+                                    (257, "9pt")])
 @pytest.mark.parametrize("seg_lines", [0, 5, 1000, "tile"])
 def test_fused_post_smoothing_with_the_correction_folded_in(m, kind, seg_lines):
     """lmg_stencil_smooth_prolong / lmg_stencil_smooth_tiled_prolong: x_out = J^S(x + P e) in one pass, against the
@@ -1226,7 +1238,7 @@ def test_fused_post_smoothing_with_the_correction_folded_in(m, kind, seg_lines):
         ops.set_tiled_enabled(True)
 
 
-@pytest.mark.parametrize("m,kind", [(64, "5pt"), (150, "5pt"), (64, "9pt"), (129, "9pt")])
+@pytest.mark.parametrize("m,kind", [(64, "5pt"), (150, "5pt"), (64, "9pt"), (129, "9pt"), (300, "5pt"), (301, "5pt"), (257, "9pt")])
 @pytest.mark.parametrize("seg_lines", [0, 5, 6, 1000, "tile"])
 def test_fused_pre_smoothing_with_the_restriction_folded_in(m, kind, seg_lines):
     """lmg_stencil_smooth_restrict: x_out = J^S(x), b_c = R (b - A x_out) in one pass without storing the residual,

@@ -16,6 +16,7 @@
 // a few per cent for the near-uniform rows this format is used for.
 #include "lmg_common.hpp"
 #include <limits.h>
+#include <string.h>
 
 namespace {
 
@@ -41,7 +42,9 @@ struct SArgs {
     double *partial;
 };
 
-template <int MODE, bool COL16, int JU>
+// NT: the entry streams (columns, values) are read once per sweep: nontemporal loads keep them from evicting the
+// vector lines the gathers of x live on (L2)
+template <int MODE, bool COL16, int JU, bool NT = false>
 __global__ void __launch_bounds__(kBlock) sell_sweep_kernel(SArgs a)
 {
     __shared__ double s_red[kBlock / LMG_WAVE];
@@ -67,8 +70,9 @@ __global__ void __launch_bounds__(kBlock) sell_sweep_kernel(SArgs a)
 #pragma unroll
             for (int jj = 0; jj < JU; ++jj) {
                 const int j = (j0 + jj < slen) ? j0 + jj : slen - 1;      // padded storage: always readable
-                c[jj] = cb + (int)col[base + (long long)j * LMG_WAVE];
-                v[jj] = a.val[base + (long long)j * LMG_WAVE];
+                const long long e = base + (long long)j * LMG_WAVE;
+                c[jj] = cb + (int)(NT ? __builtin_nontemporal_load(col + e) : col[e]);
+                v[jj] = NT ? __builtin_nontemporal_load(a.val + e) : a.val[e];
             }
 #pragma unroll
             for (int jj = 0; jj < JU; ++jj) xv[jj] = a.x[(j0 + jj < len) ? c[jj] : 0];
@@ -182,18 +186,40 @@ __global__ void __launch_bounds__(kBlock) sell_fill_kernel(int64_t n, int64_t ns
     }
 }
 
+// measured (tools/time_sell.py, Jacobi sweep): 2049^2 x 25 entries (1.05 GB) 0.264 -> 0.250 ms, 1025^2 x 49 (0.51 GB)
+// 0.122 -> 0.114 ms, but 721^2 x 25 (0.13 GB: the whole matrix stays in the Infinity Cache) 0.025 -> 0.032 ms
+int g_sell_nt = -1;                       // -1: by size, 0: never, 1: always
+int64_t g_sell_nt_entries = 30000000;     // padded entries from which the streams no longer fit the 256 MB Infinity Cache
+
 template <int MODE, bool COL16>
 int launch(SArgs a, int max_len, hipStream_t st)
 {
     // measured on MI355X (tools/tune_sweep.py --matrix L1|L2): see DESIGN.md
     const dim3 grid((unsigned)(a.blocks_per_xcd * 8)), block(kBlock);
+    const bool nt = g_sell_nt == 1 || (g_sell_nt < 0 && (int64_t)a.n * max_len >= g_sell_nt_entries);
     if (max_len <= 12) hipLaunchKernelGGL((sell_sweep_kernel<MODE, COL16, 4>), grid, block, 0, st, a);
+    else if (nt) hipLaunchKernelGGL((sell_sweep_kernel<MODE, COL16, 8, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((sell_sweep_kernel<MODE, COL16, 8>), grid, block, 0, st, a);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }
 
 }  // namespace
+
+int lmg_sell_tune_set(const char *key, int v)
+{
+    if (strcmp(key, "sell_nt") == 0) {
+        if (v < -1 || v > 1) return LMG_ERR_ARG;
+        g_sell_nt = v;
+        return LMG_OK;
+    }
+    return LMG_ERR_ARG;
+}
+int lmg_sell_tune_get(const char *key)
+{
+    if (strcmp(key, "sell_nt") == 0) return g_sell_nt;
+    return LMG_ERR_ARG;
+}
 
 extern "C" {
 

@@ -19,6 +19,8 @@ int lmg_tile_tune_set(const char *key, int v);
 int lmg_tile_tune_get(const char *key);
 int lmg_dia_tune_set(const char *key, int v);
 int lmg_dia_tune_get(const char *key);
+int lmg_sell_tune_set(const char *key, int v);
+int lmg_sell_tune_get(const char *key);
 int lmg_gsw_tune_set(const char *key, int v);
 int lmg_gsw_tune_get(const char *key);
 int lmg_gs_tune_set(int v);
@@ -674,6 +676,7 @@ int lmg_tune_set(const char *key, int value)
     if (strncmp(key, "fused_", 6) == 0) return lmg_fused_tune_set(key, value);
     if (strncmp(key, "tile_", 5) == 0) return lmg_tile_tune_set(key, value);
     if (strncmp(key, "dia_", 4) == 0) return lmg_dia_tune_set(key, value);
+    if (strncmp(key, "sell_", 5) == 0) return lmg_sell_tune_set(key, value);
     if (strncmp(key, "gsw_", 4) == 0) return lmg_gsw_tune_set(key, value);
     if (strcmp(key, "gs_single_max") == 0) return lmg_gs_tune_set(value);
     return LMG_ERR_ARG;
@@ -690,6 +693,7 @@ int lmg_tune_get(const char *key)
     if (strncmp(key, "fused_", 6) == 0) return lmg_fused_tune_get(key);
     if (strncmp(key, "tile_", 5) == 0) return lmg_tile_tune_get(key);
     if (strncmp(key, "dia_", 4) == 0) return lmg_dia_tune_get(key);
+    if (strncmp(key, "sell_", 5) == 0) return lmg_sell_tune_get(key);
     if (strncmp(key, "gsw_", 4) == 0) return lmg_gsw_tune_get(key);
     if (strcmp(key, "gs_single_max") == 0) return lmg_gs_tune_get();
     return LMG_ERR_ARG;

@@ -333,7 +333,13 @@ __device__ __forceinline__ void fused_march(const MArgs &a, const Tables &T, con
     auto fetch = [&](int y, Line &L) {
         if (FAST) {
             // all of it in range: scalar row base + lane offset, nothing to clamp or to mark
+#ifdef LMG_FUSED_HALOPROBE
+            // TIMING PROBE (wrong results): halo lines are read from the segment's own first / last line -- the same
+            // instructions, but no line is fetched by two waves
+            const int64_t i0 = (int64_t)min(max(y, out_y0), out_y1 - 1) * W + c0;
+#else
             const int64_t i0 = (int64_t)y * W + c0;
+#endif
             L.ok = 3;
             unsigned short two;
             __builtin_memcpy(&two, reinterpret_cast<const char *>(a.pid + i0) + lane2, 2);

@@ -687,7 +687,9 @@ __device__ __forceinline__ void fused_march(const MArgs &a, const Tables &T, con
 }
 
 template <int S, unsigned UM, bool RESID, bool ZERO, int PF, bool PROL = false, bool REST = false>
-__global__ void __launch_bounds__(kBlock, 3) stencil_fused_kernel(MArgs a)
+// (the restricting pass of three sweeps needs 172 VGPRs: capped at 168 it spilled an address of the general body and lost
+// scheduling freedom everywhere -- measured on one box 0.149 ms at 3 waves / SIMD against 0.138 at 2 with 2 560 waves)
+__global__ void __launch_bounds__(kBlock, (REST && S >= 3) ? 2 : 3) stencil_fused_kernel(MArgs a)
 {
     static_assert(!PROL || (!RESID && !ZERO), "the correction is fused into post-smoothing passes only");
     static_assert(!REST || (RESID && !PROL), "the restriction replaces the store of the residual");
@@ -759,6 +761,7 @@ int g_fused_pf = 0;             // 0 = default
 int g_fused_seg_lines_prol = 0; // segment length of the passes with the correction / the restriction folded in (0 = like the others)
 int g_fused_seg_lines_rest = 0;
 int g_fused_want_waves = 5120;  // waves a launch aims at when it cuts the lines into segments ...
+int g_fused_want_waves_rest3 = 2560;   // ... the restricting pass of three sweeps (2 waves / SIMD): 1.25 rounds of ITS slots
 int g_fused_floor_halos = 4;    // ... which are never shorter than this many halos (the redundant lines of a segment: 2 H)
 int g_fused_balance = 1;        // shorter segments for the items that run the slower bodies (boundary strips, first / last segment)
 int g_fused_slow_pct = 55;      // their steps, per cent of a normal item's
@@ -781,7 +784,7 @@ int launch4(MArgs a, hipStream_t st)
     if (seg_lines <= 0) {
         // (round 2 gave the pass with the restriction folded in one round of waves with 48-line segments; with the
         // balanced decomposition 28 lines measure best for it too: cycle 0.500 vs 0.509 ms)
-        const int want = g_fused_want_waves;
+        const int want = (REST && S >= 3 && !ZERO) ? g_fused_want_waves_rest3 : g_fused_want_waves;
         const int want_segs = (want + a.strips - 1) / a.strips;
         seg_lines = (a.lines + want_segs - 1) / want_segs;
         const int floor_lines = H > 0 ? g_fused_floor_halos * H : 4;
@@ -885,6 +888,11 @@ int lmg_fused_tune_set(const char *key, int v)
         g_fused_seg_max_lines = v;
         return LMG_OK;
     }
+    if (strcmp(key, "fused_want_waves_rest3") == 0) {
+        if (v < 1) return LMG_ERR_ARG;
+        g_fused_want_waves_rest3 = v;
+        return LMG_OK;
+    }
     if (strcmp(key, "fused_want_waves") == 0) {
         if (v < 1) return LMG_ERR_ARG;
         g_fused_want_waves = v;
@@ -916,6 +924,7 @@ int lmg_fused_tune_get(const char *key)
     if (strcmp(key, "fused_seg_lines_prol") == 0) return g_fused_seg_lines_prol;
     if (strcmp(key, "fused_seg_lines_rest") == 0) return g_fused_seg_lines_rest;
     if (strcmp(key, "fused_want_waves") == 0) return g_fused_want_waves;
+    if (strcmp(key, "fused_want_waves_rest3") == 0) return g_fused_want_waves_rest3;
     if (strcmp(key, "fused_floor_halos") == 0) return g_fused_floor_halos;
     if (strcmp(key, "fused_balance") == 0) return g_fused_balance;
     if (strcmp(key, "fused_fast") == 0) return g_fused_fast;

@@ -15,6 +15,7 @@ ap.add_argument("--size", type=int, default=4096)
 ap.add_argument("--set", action="append", default=[], help="comma-separated key=value tune settings of one run ('base' = none)")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--kinds", default="rest,prol,resid,plain")
+ap.add_argument("--sweeps", type=int, default=3)
 a = ap.parse_args()
 m = a.size
 dev = torch.device("cuda:0")
@@ -31,10 +32,10 @@ x = torch.rand(n, dtype=torch.float64, device=dev); b = torch.rand_like(x); y = 
 e = torch.rand(nc, dtype=torch.float64, device=dev); bc = torch.empty_like(e)
 assert ops.stencil_smooth_prolong_available(fa, lev.P) and ops.stencil_smooth_restrict_available(fa, lev.R)
 calls = {
-    "rest": (lambda: ops.stencil_smooth(fa, x, b, 0.8, 3, y, None, restrict=(lev.R, bc)), n * 25 + nc * 9),
-    "prol": (lambda: ops.stencil_smooth(fa, x, b, 0.8, 3, y, None, prolong=(lev.P, e)), n * 26 + nc * 8),
-    "resid": (lambda: ops.stencil_smooth(fa, x, b, 0.8, 3, y, r), n * 33),
-    "plain": (lambda: ops.stencil_smooth(fa, x, b, 0.8, 3, y, None), n * 25),
+    "rest": (lambda: ops.stencil_smooth(fa, x, b, 0.8, a.sweeps, y, None, restrict=(lev.R, bc)), n * 25 + nc * 9),
+    "prol": (lambda: ops.stencil_smooth(fa, x, b, 0.8, a.sweeps, y, None, prolong=(lev.P, e)), n * 26 + nc * 8),
+    "resid": (lambda: ops.stencil_smooth(fa, x, b, 0.8, a.sweeps, y, r), n * 33),
+    "plain": (lambda: ops.stencil_smooth(fa, x, b, 0.8, a.sweeps, y, None), n * 25),
 }
 
 

@@ -761,7 +761,8 @@ int g_fused_pf = 0;             // 0 = default
 int g_fused_seg_lines_prol = 0; // segment length of the passes with the correction / the restriction folded in (0 = like the others)
 int g_fused_seg_lines_rest = 0;
 int g_fused_want_waves = 5120;  // waves a launch aims at when it cuts the lines into segments ...
-int g_fused_want_waves_rest3 = 2560;   // ... the restricting pass of three sweeps (2 waves / SIMD): 1.25 rounds of ITS slots
+int g_fused_want_waves_rest3 = 2700;   // ... the restricting pass of three sweeps (2 waves / SIMD: 2 048 slots); in the cfg#4 cycle 52 - 54-line
+                                       // segments measure 0.486 ms, 44 - 50 and 56 - 58 lines 0.489 - 0.495, 28 lines 0.511
 int g_fused_floor_halos = 4;    // ... which are never shorter than this many halos (the redundant lines of a segment: 2 H)
 int g_fused_balance = 1;        // shorter segments for the items that run the slower bodies (boundary strips, first / last segment)
 int g_fused_slow_pct = 55;      // their steps, per cent of a normal item's

@@ -65,6 +65,10 @@ PMC_TRAFFIC.update({
     (4096, "fused_restrict"): (689422541, "profiles/r03_fused_pass_pmc_fetch_write.txt"),
     (4096, "fused_prolong"): (666776781, "profiles/r03_fused_pass_pmc_fetch_write.txt"),
 })
+# end of round 3: the restricting pass at 2 waves / SIMD with 53-line segments: 2 x 206 378.6 KB + 165 656.2 KB
+PMC_TRAFFIC.update({
+    (4096, "fused_restrict"): (592295206, "profiles/r03b_fused_pass_pmc_fetch_write.txt"),
+})
 
 
 def sweep_bytes(n, nnz):

@@ -65,9 +65,11 @@ PMC_TRAFFIC.update({
     (4096, "fused_restrict"): (689422541, "profiles/r03_fused_pass_pmc_fetch_write.txt"),
     (4096, "fused_prolong"): (666776781, "profiles/r03_fused_pass_pmc_fetch_write.txt"),
 })
-# end of round 3: the restricting pass at 2 waves / SIMD with 53-line segments: 2 x 206 378.6 KB + 165 656.2 KB
+# end of round 3: the passes with a transfer folded in on 53-line segments (the restricting one at 2 waves / SIMD):
+# 2 x 206 175.1 KB + 165 646.8 KB; 2 x 217 409.6 KB + 133 377.5 KB
 PMC_TRAFFIC.update({
-    (4096, "fused_restrict"): (592295206, "profiles/r03b_fused_pass_pmc_fetch_write.txt"),
+    (4096, "fused_restrict"): (591868818, "profiles/r03b_fused_pass_pmc_fetch_write.txt"),
+    (4096, "fused_prolong"): (581833420, "profiles/r03b_fused_pass_pmc_fetch_write.txt"),
 })
 
 

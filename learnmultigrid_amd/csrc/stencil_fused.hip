@@ -777,7 +777,7 @@ int g_fused_pf = 0;             // 0 = default
 int g_fused_seg_lines_prol = 0; // segment length of the passes with the correction / the restriction folded in (0 = like the others)
 int g_fused_seg_lines_rest = 0;
 int g_fused_want_waves = 5120;  // waves a launch aims at when it cuts the lines into segments ...
-int g_fused_want_waves_rest3 = 2700;   // ... the restricting pass of three sweeps (2 waves / SIMD: 2 048 slots); in the cfg#4 cycle 52 - 54-line
+int g_fused_want_waves_rest3 = 2700;   // ... the passes of three sweeps with a transfer folded in (restricting: 2 waves / SIMD); in the cfg#4 cycle 52 - 54-line
                                        // segments measure 0.486 ms, 44 - 50 and 56 - 58 lines 0.489 - 0.495, 28 lines 0.511
 int g_fused_floor_halos = 4;    // ... which are never shorter than this many halos (the redundant lines of a segment: 2 H)
 int g_fused_balance = 1;        // shorter segments for the items that run the slower bodies (boundary strips, first / last segment)
@@ -801,7 +801,8 @@ int launch4(MArgs a, hipStream_t st)
     if (seg_lines <= 0) {
         // (round 2 gave the pass with the restriction folded in one round of waves with 48-line segments; with the
         // balanced decomposition 28 lines measure best for it too: cycle 0.500 vs 0.509 ms)
-        const int want = (REST && S >= 3 && !ZERO) ? g_fused_want_waves_rest3 : g_fused_want_waves;
+        // (the correcting pass too: in the cfg#4 cycle 53-line segments 0.4796 ms, 28 lines 0.486, 20 - 56 lines 0.482 - 0.494)
+        const int want = ((REST || PROL) && S >= 3 && !ZERO) ? g_fused_want_waves_rest3 : g_fused_want_waves;
         const int want_segs = (want + a.strips - 1) / a.strips;
         seg_lines = (a.lines + want_segs - 1) / want_segs;
         const int floor_lines = H > 0 ? g_fused_floor_halos * H : 4;

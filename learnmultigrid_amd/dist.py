@@ -683,7 +683,11 @@ class DistributedVCycle:
         return math.sqrt(self.norm2.item())
 
     def make_step(self, smoother, steps, omega, graph=False):
-        # RCCL point-to-point inside a captured hipGraph is left for a later round: eager launches
+        """One V-cycle as a callable.  `graph` is accepted for symmetry with Hierarchy.captured_cycle: the replicated tail
+        below the distributed levels always replays from a hipGraph (`use_tail_graph`); the kernel segments between two
+        messages of the distributed levels are launched eagerly -- capturing each of them was measured at world size 1
+        (2049^2: 0.592 ms with segment graphs vs 0.576 eager) and dropped, RCCL point-to-point inside a captured graph has
+        not been tried on this pool."""
         def step():
             self.cycle(smoother, steps, omega)
         return step

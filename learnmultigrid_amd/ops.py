@@ -1227,7 +1227,11 @@ def stencil_gs_available(A):
 
 def stencil_gs(A, x, b, sweeps=1):
     """`sweeps` exact forward (lexicographic) Gauss-Seidel sweeps in place on x (lmg_stencil_gs_sweep): the
-    bits of csr_gs_schedule on the level schedule, without a schedule."""
+    bits of csr_gs_schedule on the level schedule, without a schedule.
+
+    The band tickets and progress counters live in ONE work buffer per operator (`StencilTwin._gs_work`): sweeps on the same
+    operator must be ordered on one stream (the hierarchy's launch stream); two streams sweeping one operator at the same
+    time would race on the counters."""
     _vec_ok(x, b)
     S = A.stencil
     if S is None or not S.gs_ok:

@@ -340,7 +340,7 @@ template <unsigned UM>
 __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
 {
     static_assert(!(UM & 4u), "bands staged through LDS: operators without the upper-right slot");
-    __shared__ __attribute__((aligned(16))) unsigned char s_tile[kNCH * kSlotBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char s_tile[kNCH * kSlotBytes + LMG_WAVE * 8];   // + one dump slot per lane
     __shared__ double s_val[kMaxPat * 9];
     __shared__ int s_mask[kMaxPat];
     __shared__ int s_band;
@@ -493,6 +493,9 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
     double O0 = 0.0, O1 = 0.0;                // old values of the own line at x, x+1
     double R = 0.0;                           // own result of the previous step = new (y, x-1)
     int flushed = -1;                         // last chunk whose stores have completed and been published
+    const unsigned w_dump = (unsigned)(kNCH * kSlotBytes) + (unsigned)lane * 8u;
+    unsigned w_addr = w_dump;                 // the previous step's result, written to the tile at the top of the next step
+    double w_val = 0.0;
     int issued_flush = -1;
     const int T_end = W + last_lane;          // steps: the last line relaxes column W - 1 at step W - 1 + last_lane
     In nxt = read_inputs(-1 - lane);          // (warm-up of the windows: column x + 1 = 0 for lane 0)
@@ -522,6 +525,7 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
         }
         const In cur = nxt;
         const int x = t - lane;
+        *reinterpret_cast<double *>(s_tile + w_addr) = w_val;               // (the previous step's result; a lane without one writes its dump slot)
         nxt = read_inputs(x + 1);
         // ---- windows move one column to the right -----------------------------------------------------------------------
         const double inU = dpp_lower(R);                               // lane l-1's result of the previous step = new (y-1, x)
@@ -565,8 +569,15 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
             xn = diag != 0.0 ? q_ : O0;
             R = act ? xn : R;
         }
-        if (act) *reinterpret_cast<double *>(s_tile + taddr(rowoff, frow, x)) = xn;     // the new value replaces the old one in the tile
+        // the new value replaces the old one in the tile -- ONE STEP LATER (at the top of the next step): the write hangs at the
+        // end of the step's dependent chain, and with it at the end of the step the next step's first wait for LDS data also
+        // waited for this write (measured: the sweep without the write 4.0 instead of 6.7 ms).  Nothing reads the tile copy of a
+        // new value before its chunk is flushed (lane l + 1 gets it by DPP), and the chunk that leaves at the top of a period
+        // ends 64 columns before the columns still pending.  No branch around the write: an inactive lane writes a dump slot.
+        w_addr = act ? taddr(rowoff, frow, x) : w_dump;
+        w_val = xn;
     }
+    *reinterpret_cast<double *>(s_tile + w_addr) = w_val;
     // the chunks still in the ring leave, then everything of this band is done
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     for (int fc = issued_flush + 1; fc <= cmax; ++fc) flush_chunk(fc);

@@ -911,7 +911,7 @@ def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None, prolong=None, r
         _vec_ok(bc)
         if T is None or r_out is not None or prolong is not None or T.n != S.n or T.W != S.W or bc.numel() != T.nc:
             raise LmgError("stencil_smooth: this restriction cannot be fused into the pass")
-        if _fused_kind(A) == "tile":
+        if _fused_kind(A) == "tile" and not (S.n >= REG_RESTRICT_MIN_ROWS and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask)):
             check(_lib.lib().lmg_stencil_smooth_tiled_restrict(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask,
                                                                S.hot, hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out),
                                                                T.nc, T.Wc, _p(bc), _p(T.pid), T.npat, _p(T.r_val), _p(T.r_mask),
@@ -929,7 +929,7 @@ def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None, prolong=None, r
         _vec_ok(e)
         if T is None or r_out is not None or x_in is None or T.n != S.n or T.W != S.W or e.numel() != T.nc:
             raise LmgError("stencil_smooth: this prolongation cannot be fused into the pass")
-        if _fused_kind(A) == "tile":
+        if _fused_kind(A) == "tile" and not (S.n >= REG_PROLONG_MIN_ROWS and _lib.lib().lmg_stencil_smooth_prolong_supported(S.umask)):
             check(_lib.lib().lmg_stencil_smooth_tiled_prolong(S.n, S.W, _p(S.pid), S.npat, _p(S.st_val), _p(S.st_mask), S.umask,
                                                               S.hot, hv, int(sweeps), _p(x_in), _p(b), float(omega), _p(x_out),
                                                               T.nc, T.Wc, _p(e), _p(T.pid), T.npat, _p(T.p_val), _p(T.p_mask),
@@ -956,6 +956,10 @@ def stencil_smooth(A, x_in, b, omega, sweeps, x_out, r_out=None, prolong=None, r
 # passes are bound by their arithmetic and the extra work costs more than the two small launches it replaces
 # (measured in the cycle, cfg#4: 4097^2 5-point -52 us and -7 us, 2049^2 9-point +8 us and +4 us).
 FUSED_TRANSFER_MIN_ROWS = 12_000_000
+# Levels that run the tiled passes may still take the REGISTER pass for the launch with the correction / the restriction
+# folded in from this many rows on (A/B knobs; see DESIGN.md section 4 for what was measured).
+REG_PROLONG_MIN_ROWS = 1 << 62
+REG_RESTRICT_MIN_ROWS = 1 << 62
 _FUSED_PROLONG_ENABLED = True
 
 

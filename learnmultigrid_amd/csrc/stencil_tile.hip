@@ -329,10 +329,12 @@ __global__ void __launch_bounds__(RR / RBV * LMG_WAVE, (RR / RBV == 16 && !PROL)
     }
 }
 
-int g_tile_rows = 0;        // 0 = chosen per launch (tuning: 16, 32)
+int g_tile_rows = 16;       // lines per tile (16, 32; 0 = 32) on grids of fewer than g_tile_big_lines lines: more, smaller workgroups
+                            // where a level is a handful of tiles (cfg#4 cycle 0.4725 -> 0.4687 ms, 1025^2 / 4 levels 0.1150 -> 0.1103,
+                            // cfg#2 0.0728 -> 0.0706)
 int g_tile_prol_wide_lines = 768;    // grids of at least this many lines: the pass with the correction on 8-wave workgroups
-int g_tile_rows_big = 0;    // the same for grids of at least g_tile_big_lines lines (tuning one level of a cycle)
-int g_tile_big_lines = 0x7fffffff;
+int g_tile_rows_big = 0;    // the same for grids of at least g_tile_big_lines lines
+int g_tile_big_lines = 600;
 
 template <int S, unsigned UM, bool RESID, bool ZERO, int RR, bool PROL = false, bool REST = false, int RBV = kRB>
 int launch5(TArgs a, hipStream_t st)

@@ -1145,6 +1145,7 @@ def test_fused_stencil_smoothing_equals_separate_sweeps(name, seg_lines, pf):
     rng = np.random.default_rng(77)
     x0, b = rng.standard_normal(n), rng.standard_normal(n)
     min_tiled = ops.TILED_MIN_ROWS
+    tile_rows0 = ops.tune_get("tile_rows")
     try:
         if tiled:
             ops.TILED_MIN_ROWS = 0
@@ -1175,7 +1176,7 @@ def test_fused_stencil_smoothing_equals_separate_sweeps(name, seg_lines, pf):
     finally:
         ops.tune_set("fused_seg_lines", 0)
         ops.tune_set("fused_pf", 0)
-        ops.tune_set("tile_rows", 0)
+        ops.tune_set("tile_rows", tile_rows0)
         ops.set_tiled_enabled(True)
         ops.TILED_MIN_ROWS = min_tiled
 

@@ -498,10 +498,16 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
     double w_val = 0.0;
     int issued_flush = -1;
     const int T_end = W + last_lane;          // steps: the last line relaxes column W - 1 at step W - 1 + last_lane
-    In nxt = read_inputs(-1 - lane);          // (warm-up of the windows: column x + 1 = 0 for lane 0)
+    // One chunk period (16 steps) per trip, unrolled: the position in the period is a compile-time number -- no per-step tests for
+    // the periodic work, the five windows rotate by renaming, LDS reads of later steps can move up.  The march starts a period
+    // early (steps -16 .. -2 are idle for every lane: x < -1) so that the periods stay aligned with the chunks.
+    In nxt = read_inputs(-kCW - lane);
     // every lane needs old (y, 0) / (y+1, 0) when it starts: the step before its first one reads them (x = -1)
-    for (int t = -1; t < T_end; ++t) {
-        if (t >= 0 && (t & (kCW - 1)) == 0) {
+    for (int tb = -kCW; tb < T_end; tb += kCW) {
+#pragma unroll
+      for (int u = 0; u < kCW; ++u) {
+        const int t = tb + u;
+        if (u == 0 && t >= 0) {
             // lane 0 enters chunk p: chunk p - 5 is complete and leaves; chunk p + 2 is requested -- and the line above of
             // chunk p + 1 (one chunk less ahead: what this band waits for is the band above, so it asks as late as it can)
             const int p = t >> 4;
@@ -513,7 +519,7 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
             wait_prev(p + kLead - 1);
             issue_chunk(p + kLead, false);
             issue_up(p + kLead - 1);
-        } else if (t >= 0 && (t & (kCW - 1)) == 6) {
+        } else if (u == 6 && t >= 0) {
             // six steps later everything requested at the top of the period has landed and the flush stores are done:
             // publish them (the band below waits for exactly this), and look at the band above now for the next period
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -576,6 +582,7 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
         // ends 64 columns before the columns still pending.  No branch around the write: an inactive lane writes a dump slot.
         w_addr = act ? taddr(rowoff, frow, x) : w_dump;
         w_val = xn;
+      }
     }
     *reinterpret_cast<double *>(s_tile + w_addr) = w_val;
     // the chunks still in the ring leave, then everything of this band is done
@@ -606,6 +613,7 @@ int launch(GArgs a, hipStream_t st)
 
 int g_gs_max_sweeps = kMaxSweeps;           // sweeps pipelined in one launch (1 = a launch per sweep)
 int g_gs_multi_max_rows = 8000000;          // ... on levels of at most this many rows
+int g_gs_lds_min_rows = 2500000;           // LDS bands (a launch per sweep) instead of pipelined register bands from this many rows
 int g_gs_lds = -1;                          // bands staged through LDS (gs_band_lds_kernel): -1 = where one sweep per launch runs anyway, 0 = never, 1 = wherever possible
 
 }  // namespace
@@ -694,7 +702,9 @@ int lmg_stencil_gs_sweep(int64_t n, int32_t line_stride, const uint8_t *pid, int
         // piece that straddles the end of a vector of odd length is then inside its last 16 bytes), at least one full chunk
         const bool lds_ok = !(union_mask & 4u) && (union_mask == kMask5 || union_mask == kMask7) && line_stride >= 64 &&
                             lmg_aligned16(x) && lmg_aligned16(b) && (reinterpret_cast<uintptr_t>(pid) & 3u) == 0;
-        const bool use_lds = lds_ok && (g_gs_lds == 1 || (g_gs_lds < 0 && per_launch == 1));
+        // (one sweep: 513^2 0.49 ms with LDS bands, 0.83 with register bands; three sweeps, LDS launches vs one pipelined register
+        // launch: 513^2 1.46 vs 1.21 ms, 1025^2 2.85 vs 2.45, 2049^2 5.64 vs 6.76, 4097^2 11.6 vs 22.3)
+        const bool use_lds = lds_ok && (g_gs_lds == 1 || (g_gs_lds < 0 && (per_launch == 1 || sweeps - sw == 1 || n >= g_gs_lds_min_rows)));
         if (use_lds) per_launch = 1;
         a.sweeps = sweeps - sw < per_launch ? sweeps - sw : per_launch;
         // ticket and progress counters back to zero (a memset node when captured into a hipGraph)

@@ -495,6 +495,7 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
     int flushed = -1;                         // last chunk whose stores have completed and been published
     const unsigned w_dump = (unsigned)(kNCH * kSlotBytes) + (unsigned)lane * 8u;
     unsigned w_addr = w_dump;                 // the previous step's result, written to the tile at the top of the next step
+    unsigned a_x = w_dump;                    // tile address of the element this step relaxes
     double w_val = 0.0;
     int issued_flush = -1;
     const int T_end = W + last_lane;          // steps: the last line relaxes column W - 1 at step W - 1 + last_lane
@@ -532,6 +533,7 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
         const In cur = nxt;
         const int x = t - lane;
         *reinterpret_cast<double *>(s_tile + w_addr) = w_val;               // (the previous step's result; a lane without one writes its dump slot)
+        const unsigned a_x1 = own_addr_prev;                           // tile address of (y, x + 1): what the call below reads b through
         nxt = read_inputs(x + 1);
         // ---- windows move one column to the right -----------------------------------------------------------------------
         const double inU = dpp_lower(R);                               // lane l-1's result of the previous step = new (y-1, x)
@@ -580,7 +582,8 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
         // waited for this write (measured: the sweep without the write 4.0 instead of 6.7 ms).  Nothing reads the tile copy of a
         // new value before its chunk is flushed (lane l + 1 gets it by DPP), and the chunk that leaves at the top of a period
         // ends 64 columns before the columns still pending.  No branch around the write: an inactive lane writes a dump slot.
-        w_addr = act ? taddr(rowoff, frow, x) : w_dump;
+        w_addr = act ? a_x : w_dump;                                   // (= taddr(rowoff, frow, x): the address (y, x + 1) had a step ago)
+        a_x = a_x1;
         w_val = xn;
       }
     }

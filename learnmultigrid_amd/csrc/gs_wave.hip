@@ -577,11 +577,13 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
             xn = diag != 0.0 ? q_ : O0;
             R = act ? xn : R;
         }
-        // the new value replaces the old one in the tile -- ONE STEP LATER (at the top of the next step): the write hangs at the
-        // end of the step's dependent chain, and with it at the end of the step the next step's first wait for LDS data also
-        // waited for this write (measured: the sweep without the write 4.0 instead of 6.7 ms).  Nothing reads the tile copy of a
-        // new value before its chunk is flushed (lane l + 1 gets it by DPP), and the chunk that leaves at the top of a period
-        // ends 64 columns before the columns still pending.  No branch around the write: an inactive lane writes a dump slot.
+        // the new value replaces the old one in the tile -- ONE STEP LATER (at the top of the next step), off the end of the step's
+        // dependent chain.  Nothing reads the tile copy of a new value before its chunk is flushed (lane l + 1 gets it by DPP),
+        // and the chunk that leaves at the top of a period ends 64 columns before the columns still pending.  No branch around
+        // the write: an inactive lane writes a dump slot.
+        // (Tried and dropped: a second, branch-free body for periods in which every element of chunks p - 4 .. p holds the
+        // frequent pattern -- no id read, no activity tests, no wave-uniform branch: bit-exact, but 4.30 instead of 3.69 ms at
+        // 4097^2; the two 16-step bodies no longer fit what a lone wave streams from the instruction cache.)
         w_addr = act ? a_x : w_dump;                                   // (= taddr(rowoff, frow, x): the address (y, x + 1) had a step ago)
         a_x = a_x1;
         w_val = xn;

@@ -583,7 +583,7 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
         // the write: an inactive lane writes a dump slot.
         // (Tried and dropped: a second, branch-free body for periods in which every element of chunks p - 4 .. p holds the
         // frequent pattern -- no id read, no activity tests, no wave-uniform branch: bit-exact, but 4.30 instead of 3.69 ms at
-        // 4097^2; the two 16-step bodies no longer fit what a lone wave streams from the instruction cache.)
+        // 4097^2 (twice the code for a lone wave to fetch; not investigated further).)
         w_addr = act ? a_x : w_dump;                                   // (= taddr(rowoff, frow, x): the address (y, x + 1) had a step ago)
         a_x = a_x1;
         w_val = xn;

@@ -336,7 +336,11 @@ constexpr int kFlushLag = 5;                               // chunk p - 5 is com
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr),                  \
                                      (__attribute__((address_space(3))) void *)(lptr), bytes, 0, aux)
 
-template <unsigned UM>
+// MULTI: several sweeps in one launch, pipelined like gs_wavefront_kernel<UM, true> (tickets over (sweep, band) in row-major order;
+// band b of sweep s asks for chunk c once band b + 1 of sweep s - 1 -- the last band: band b itself -- has FLUSHED chunk c: then its
+// own 64 lines and the line below hold the previous sweep's final values there, and nobody will read what this band overwrites).
+// Every line is then stored write-through and x comes in past the caches, like the line above always does.
+template <unsigned UM, bool MULTI = false>
 __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
 {
     static_assert(!(UM & 4u), "bands staged through LDS: operators without the upper-right slot");
@@ -349,8 +353,9 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
     for (int i = lane; i < a.npat; i += 64) s_mask[i] = a.st_mask[i];
     if (lane == 0) s_band = atomicAdd(&a.work[1], 1);
     __syncthreads();
-    const int band = __builtin_amdgcn_readfirstlane(s_band);
-    if (band >= a.nbands) return;
+    const int ticket = __builtin_amdgcn_readfirstlane(s_band);
+    if (ticket >= a.nbands * (MULTI ? a.sweeps : 1)) return;
+    const int sweep = MULTI ? ticket / a.nbands : 0, band = ticket - sweep * a.nbands;
 
     const int n = a.n, W = a.W;
     const int y0 = band * 64;
@@ -358,8 +363,11 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
     const bool line_ok = y < a.lines;
     const int last_lane = min(63, a.lines - 1 - y0);
     const int cmax = (W - 1) / kCW;                                   // last chunk
-    int *const prog = a.work + 3;
+    int *const prog = a.work + 3 + sweep * a.nbands;
     const int *prog_prev = band > 0 ? prog + band - 1 : a.work;
+    const bool has_old = MULTI && sweep > 0;
+    const int *prog_old = has_old ? prog - a.nbands + min(band + 1, a.nbands - 1) : a.work;
+    constexpr int kXPol = MULTI ? kSc1 : 0;                           // cache policy of the band's own loads of x
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a.x, 0, (int)((unsigned)n * 8u), 0x00020000);
 
     // ---- LDS addressing: plain rows of 128 B.  Lane l reads row l at column t - l: the SKEW of the wavefront spreads the
@@ -391,7 +399,7 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
             const int pce = q;
             const int64_t idx = (int64_t)(y0 + row) * W + col0 + 2 * pce;
             // (a piece that straddles the end of the vector is 16-byte aligned: the vectors are, and n - 1 is even there)
-            if (row <= 64 && y0 + row < a.lines && idx < n) LMG_GLDS(a.x + idx, sb + g * 1024, 16, 0);
+            if (row <= 64 && y0 + row < a.lines && idx < n) LMG_GLDS(a.x + idx, sb + g * 1024, 16, kXPol);
             if (g < 8 && y0 + row < a.lines && idx < n) LMG_GLDS(a.b + idx, sb + kXSBytes + g * 1024, 16, 0);
         }
         if (line_ok) {
@@ -420,7 +428,7 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
             u2 v2;
             v2.x = v.x;
             v2.y = v.y;
-            if (g == (last_lane >> 3)) {                              // uniform: the group with the line the next band reads
+            if (MULTI || g == (last_lane >> 3)) {                     // uniform: the group with the line the next band reads
                 __builtin_amdgcn_raw_buffer_store_b128(v, rs_x, off16, 0, kSc1);
                 __builtin_amdgcn_raw_buffer_store_b64(v2, rs_x, off8, 0, kSc1);
             } else {
@@ -441,6 +449,20 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
             --spin_budget;
             __builtin_amdgcn_s_sleep(4);
             f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(prog_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        if (f < need && lane == 0) a.work[0] = 1;
+    };
+    int flag_old_seen = 0;
+    auto wait_old = [&](int c) {                                      // chunk c of the previous sweep final (own lines, line below)?
+        if (!has_old || c > cmax) return;
+        const int need = min(W, (c + 1) * kCW);
+        int f = __builtin_amdgcn_readfirstlane(flag_old_seen);
+        if (f >= need) return;
+        f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(prog_old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        while (f < need && spin_budget > 0) {
+            --spin_budget;
+            __builtin_amdgcn_s_sleep(4);
+            f = __builtin_amdgcn_readfirstlane(__hip_atomic_load(prog_old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         }
         if (f < need && lane == 0) a.work[0] = 1;
     };
@@ -481,7 +503,10 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
     const bool hpow2 = hrc != 0.0;
 
     // prologue: the first kLead chunks (the line above: one chunk less ahead, see below)
-    for (int c = 0; c < kLead; ++c) issue_chunk(c, false);          // (only the line above depends on another band)
+    for (int c = 0; c < kLead; ++c) {
+        wait_old(c);
+        issue_chunk(c, false);                                      // (the line above depends on another band of this sweep)
+    }
     for (int c = 0; c < kLead - 1; ++c) {
         wait_prev(c);
         issue_up(c);
@@ -518,6 +543,7 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
                 issued_flush = p - kFlushLag;
             }
             wait_prev(p + kLead - 1);
+            wait_old(p + kLead);
             issue_chunk(p + kLead, false);
             issue_up(p + kLead - 1);
         } else if (u == 6 && t >= 0) {
@@ -529,6 +555,7 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
                 publish(min(W, (flushed + 1) * kCW));
             }
             flag_seen = __hip_atomic_load(prog_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (MULTI) flag_old_seen = __hip_atomic_load(prog_old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const In cur = nxt;
         const int x = t - lane;
@@ -600,7 +627,10 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
 template <unsigned UM>
 int launch_lds(GArgs a, hipStream_t st)
 {
-    hipLaunchKernelGGL((gs_band_lds_kernel<UM>), dim3((unsigned)a.nbands), dim3(64), 0, st, a);
+    if (a.sweeps > 1)
+        hipLaunchKernelGGL((gs_band_lds_kernel<UM, true>), dim3((unsigned)(a.nbands * a.sweeps)), dim3(64), 0, st, a);
+    else
+        hipLaunchKernelGGL((gs_band_lds_kernel<UM, false>), dim3((unsigned)a.nbands), dim3(64), 0, st, a);
     LMG_CHECK_LAUNCH();
     return LMG_OK;
 }
@@ -618,8 +648,9 @@ int launch(GArgs a, hipStream_t st)
 
 int g_gs_max_sweeps = kMaxSweeps;           // sweeps pipelined in one launch (1 = a launch per sweep)
 int g_gs_multi_max_rows = 8000000;          // ... on levels of at most this many rows
-int g_gs_lds_min_rows = 2500000;           // LDS bands (a launch per sweep) instead of pipelined register bands from this many rows
-int g_gs_lds = -1;                          // bands staged through LDS (gs_band_lds_kernel): -1 = where one sweep per launch runs anyway, 0 = never, 1 = wherever possible
+int g_gs_lds_min_rows = 0;                 // LDS bands instead of register bands from this many rows (gsw_lds = -1)
+int g_gs_lds_multi = 1;                     // LDS bands: sweeps of a smoothing step pipelined in one launch (0: a launch per sweep)
+int g_gs_lds = -1;                          // bands staged through LDS (gs_band_lds_kernel): -1 = wherever possible from g_gs_lds_min_rows rows, 0 = never, 1 = wherever possible
 
 }  // namespace
 
@@ -640,6 +671,11 @@ int lmg_gsw_tune_set(const char *key, int v)
         g_gs_lds = v;
         return LMG_OK;
     }
+    if (strcmp(key, "gsw_lds_multi") == 0) {
+        if (v < 0 || v > 1) return LMG_ERR_ARG;
+        g_gs_lds_multi = v;
+        return LMG_OK;
+    }
     return LMG_ERR_ARG;
 }
 int lmg_gsw_tune_get(const char *key)
@@ -647,6 +683,7 @@ int lmg_gsw_tune_get(const char *key)
     if (strcmp(key, "gsw_max_sweeps") == 0) return g_gs_max_sweeps;
     if (strcmp(key, "gsw_multi_max_rows") == 0) return g_gs_multi_max_rows;
     if (strcmp(key, "gsw_lds") == 0) return g_gs_lds;
+    if (strcmp(key, "gsw_lds_multi") == 0) return g_gs_lds_multi;
     return LMG_ERR_ARG;
 }
 
@@ -707,10 +744,11 @@ int lmg_stencil_gs_sweep(int64_t n, int32_t line_stride, const uint8_t *pid, int
         // piece that straddles the end of a vector of odd length is then inside its last 16 bytes), at least one full chunk
         const bool lds_ok = !(union_mask & 4u) && (union_mask == kMask5 || union_mask == kMask7) && line_stride >= 64 &&
                             lmg_aligned16(x) && lmg_aligned16(b) && (reinterpret_cast<uintptr_t>(pid) & 3u) == 0;
-        // (one sweep: 513^2 0.49 ms with LDS bands, 0.83 with register bands; three sweeps, LDS launches vs one pipelined register
-        // launch: 513^2 1.46 vs 1.21 ms, 1025^2 2.85 vs 2.45, 2049^2 5.64 vs 6.76, 4097^2 11.6 vs 22.3)
-        const bool use_lds = lds_ok && (g_gs_lds == 1 || (g_gs_lds < 0 && (per_launch == 1 || sweeps - sw == 1 || n >= g_gs_lds_min_rows)));
-        if (use_lds) per_launch = 1;
+        // (one sweep: 513^2 0.47 ms with LDS bands, 0.83 with register bands; three sweeps pipelined in one launch, LDS bands vs
+        // register bands: 513^2 0.63 vs 1.21 ms, 1025^2 1.08 vs 2.58, 2049^2 1.97 vs 7.7, 4097^2 3.9 vs 22.6 -- the LDS bands take
+        // every operator they can)
+        const bool use_lds = lds_ok && g_gs_lds != 0 && (g_gs_lds == 1 || n >= g_gs_lds_min_rows);
+        if (use_lds) per_launch = g_gs_lds_multi ? g_gs_max_sweeps : 1;       // (the LDS bands pipeline their sweeps at every size)
         a.sweeps = sweeps - sw < per_launch ? sweeps - sw : per_launch;
         // ticket and progress counters back to zero (a memset node when captured into a hipGraph)
         // (the error flag at [0] is cleared by the caller once and stays set)

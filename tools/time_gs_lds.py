@@ -22,6 +22,12 @@ for m in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "512,1024,2048,
     ops.tune_set("gsw_max_sweeps", 4); ops.tune_set("gsw_lds", 0)
     x = x0.clone(); ops.stencil_gs(dA, x, b, 3); torch.cuda.synchronize()
     t0 = time.perf_counter(); ops.stencil_gs(dA, x, b, 3); torch.cuda.synchronize(); t3 = time.perf_counter() - t0
+    ops.tune_set("gsw_lds", 1); ops.tune_set("gsw_lds_multi", 1)
+    xl = x0.clone(); ops.stencil_gs(dA, xl, b, 3); torch.cuda.synchronize()
+    t0 = time.perf_counter(); ops.stencil_gs(dA, xl, b, 3); torch.cuda.synchronize(); t3l = time.perf_counter() - t0
+    ops.stencil_gs_check(dA)
+    same3 = torch.equal(xl, x)
     ops.tune_set("gsw_lds", -1)
+    print("   3 sweeps pipelined, LDS bands: %.3f ms (equal bits: %s)" % (t3l * 1e3, same3))
     print("5pt %d^2: one sweep register wavefront %.3f ms, LDS bands %.3f ms (equal bits: %s); 3 sweeps pipelined (register kernel) %.3f ms"
           % (m + 1, res[0][0] * 1e3, res[1][0] * 1e3, torch.equal(res[0][1], res[1][1]), t3 * 1e3), flush=True)

@@ -343,7 +343,11 @@ constexpr int kFlushLag = 5;                               // chunk p - 5 is com
 template <unsigned UM, bool MULTI = false>
 __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
 {
-    static_assert(!(UM & 4u), "bands staged through LDS: operators without the upper-right slot");
+    // SK = 2 (the upper-right slot is coupled: 9-point operators): lane l relaxes column t - 2 l, and a band has 32 lines (lanes
+    // 32 .. 63 idle) so that the window of the skewed lanes still spans 62 columns = the 8-slot ring; the slots keep their
+    // 64-line layout.  A lone wave pays per instruction, not per lane: the idle half costs nothing.
+    constexpr int SK = (UM & 4u) ? 2 : 1;
+    constexpr int NL = SK == 2 ? 32 : 64;                             // lines of a band
     __shared__ __attribute__((aligned(16))) unsigned char s_tile[kNCH * kSlotBytes + LMG_WAVE * 8];   // + one dump slot per lane
     __shared__ double s_val[kMaxPat * 9];
     __shared__ int s_mask[kMaxPat];
@@ -358,10 +362,10 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
     const int sweep = MULTI ? ticket / a.nbands : 0, band = ticket - sweep * a.nbands;
 
     const int n = a.n, W = a.W;
-    const int y0 = band * 64;
+    const int y0 = band * NL;
     const int y = y0 + lane;
-    const bool line_ok = y < a.lines;
-    const int last_lane = min(63, a.lines - 1 - y0);
+    const bool line_ok = lane < NL && y < a.lines;
+    const int last_lane = min(NL - 1, a.lines - 1 - y0);
     const int cmax = (W - 1) / kCW;                                   // last chunk
     int *const prog = a.work + 3 + sweep * a.nbands;
     const int *prog_prev = band > 0 ? prog + band - 1 : a.work;
@@ -399,8 +403,8 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
             const int pce = q;
             const int64_t idx = (int64_t)(y0 + row) * W + col0 + 2 * pce;
             // (a piece that straddles the end of the vector is 16-byte aligned: the vectors are, and n - 1 is even there)
-            if (row <= 64 && y0 + row < a.lines && idx < n) LMG_GLDS(a.x + idx, sb + g * 1024, 16, kXPol);
-            if (g < 8 && y0 + row < a.lines && idx < n) LMG_GLDS(a.b + idx, sb + kXSBytes + g * 1024, 16, 0);
+            if (row <= NL && y0 + row < a.lines && idx < n) LMG_GLDS(a.x + idx, sb + g * 1024, 16, kXPol);
+            if (row < NL && y0 + row < a.lines && idx < n) LMG_GLDS(a.b + idx, sb + kXSBytes + g * 1024, 16, 0);
         }
         if (line_ok) {
             const unsigned char *src = a.pid + ((int64_t)y * W - palign) + col0;
@@ -489,7 +493,12 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
         const unsigned sbo = (((unsigned)x >> 4) & (kNCH - 1)) * kSlotBytes;
         const unsigned o = palign + ((unsigned)x & 15u);
         I.p = (int)s_tile[sbo + kXSBytes + kBSBytes + (o >> 2) * 256u + (unsigned)lane * 4u + (o & 3u)];
-        I.up = ldsd(sbo + kXSBytes + kBSBytes + kPSBytes + ((unsigned)x & 15u) * 8u);
+        if (SK == 1) {
+            I.up = ldsd(sbo + kXSBytes + kBSBytes + kPSBytes + ((unsigned)x & 15u) * 8u);
+        } else {                                                      // the line above at column x + 1 (its upper-right neighbour)
+            const unsigned xu = (unsigned)(x + 1);
+            I.up = ldsd(((xu >> 4) & (kNCH - 1)) * kSlotBytes + kXSBytes + kBSBytes + kPSBytes + (xu & 15u) * 8u);
+        }
         return I;
     };
 
@@ -513,7 +522,7 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    double U0 = 0.0, U1 = 0.0;                // new values of the line above at columns x-1, x
+    double U0 = 0.0, U1 = 0.0, U2 = 0.0;      // new values of the line above at columns x-1, x (SK = 2: and x+1)
     double D0 = 0.0, D1 = 0.0, D2 = 0.0;      // old values of the line below at x-1, x, x+1
     double O0 = 0.0, O1 = 0.0;                // old values of the own line at x, x+1
     double R = 0.0;                           // own result of the previous step = new (y, x-1)
@@ -523,11 +532,11 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
     unsigned a_x = w_dump;                    // tile address of the element this step relaxes
     double w_val = 0.0;
     int issued_flush = -1;
-    const int T_end = W + last_lane;          // steps: the last line relaxes column W - 1 at step W - 1 + last_lane
+    const int T_end = W + SK * last_lane;     // steps: the last line relaxes column W - 1 at step W - 1 + SK last_lane
     // One chunk period (16 steps) per trip, unrolled: the position in the period is a compile-time number -- no per-step tests for
     // the periodic work, the five windows rotate by renaming, LDS reads of later steps can move up.  The march starts a period
     // early (steps -16 .. -2 are idle for every lane: x < -1) so that the periods stay aligned with the chunks.
-    In nxt = read_inputs(-kCW - lane);
+    In nxt = read_inputs(-kCW - SK * lane);
     // every lane needs old (y, 0) / (y+1, 0) when it starts: the step before its first one reads them (x = -1)
     for (int tb = -kCW; tb < T_end; tb += kCW) {
 #pragma unroll
@@ -558,14 +567,19 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
             if (MULTI) flag_old_seen = __hip_atomic_load(prog_old, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const In cur = nxt;
-        const int x = t - lane;
+        const int x = t - SK * lane;
         *reinterpret_cast<double *>(s_tile + w_addr) = w_val;               // (the previous step's result; a lane without one writes its dump slot)
         const unsigned a_x1 = own_addr_prev;                           // tile address of (y, x + 1): what the call below reads b through
         nxt = read_inputs(x + 1);
         // ---- windows move one column to the right -----------------------------------------------------------------------
         const double inU = dpp_lower(R);                               // lane l-1's result of the previous step = new (y-1, x)
         U0 = U1;
-        U1 = (lane == 0) ? cur.up : inU;
+        if (SK == 2) {
+            U1 = U2;
+            U2 = (lane == 0) ? cur.up : inU;                           // lane l-1 relaxed column x + 1 a step ago
+        } else {
+            U1 = (lane == 0) ? cur.up : inU;
+        }
         D0 = D1;
         D1 = D2;
         D2 = cur.down2;
@@ -577,6 +591,7 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
             double rsum = 0.0;
             if ((UM >> 0) & 1u) rsum = rsum + hv[0] * U0;
             if ((UM >> 1) & 1u) rsum = rsum + hv[1] * U1;
+            if ((UM >> 2) & 1u) rsum = rsum + hv[2] * U2;
             if ((UM >> 3) & 1u) rsum = rsum + hv[3] * R;
             if ((UM >> 5) & 1u) rsum = rsum + hv[5] * O1;
             if ((UM >> 6) & 1u) rsum = rsum + hv[6] * D0;
@@ -594,6 +609,7 @@ __global__ void __launch_bounds__(64) gs_band_lds_kernel(GArgs a)
             double t_;
             if ((UM >> 0) & 1u) { t_ = rsum + vv[0] * U0; rsum = ((m >> 0) & 1) ? t_ : rsum; }
             if ((UM >> 1) & 1u) { t_ = rsum + vv[1] * U1; rsum = ((m >> 1) & 1) ? t_ : rsum; }
+            if ((UM >> 2) & 1u) { t_ = rsum + vv[2] * U2; rsum = ((m >> 2) & 1) ? t_ : rsum; }
             if ((UM >> 3) & 1u) { t_ = rsum + vv[3] * R; rsum = ((m >> 3) & 1) ? t_ : rsum; }
             if ((UM >> 5) & 1u) { t_ = rsum + vv[5] * O1; rsum = ((m >> 5) & 1) ? t_ : rsum; }
             if ((UM >> 6) & 1u) { t_ = rsum + vv[6] * D0; rsum = ((m >> 6) & 1) ? t_ : rsum; }
@@ -649,6 +665,7 @@ int launch(GArgs a, hipStream_t st)
 int g_gs_max_sweeps = kMaxSweeps;           // sweeps pipelined in one launch (1 = a launch per sweep)
 int g_gs_multi_max_rows = 8000000;          // ... on levels of at most this many rows
 int g_gs_lds_min_rows = 0;                 // LDS bands instead of register bands from this many rows (gsw_lds = -1)
+int g_gs_lds9 = 1;                          // LDS bands for 9-point operators too (32-line bands, two columns of skew per lane)
 int g_gs_lds_multi = 1;                     // LDS bands: sweeps of a smoothing step pipelined in one launch (0: a launch per sweep)
 int g_gs_lds = -1;                          // bands staged through LDS (gs_band_lds_kernel): -1 = wherever possible from g_gs_lds_min_rows rows, 0 = never, 1 = wherever possible
 
@@ -671,6 +688,11 @@ int lmg_gsw_tune_set(const char *key, int v)
         g_gs_lds = v;
         return LMG_OK;
     }
+    if (strcmp(key, "gsw_lds9") == 0) {
+        if (v < 0 || v > 1) return LMG_ERR_ARG;
+        g_gs_lds9 = v;
+        return LMG_OK;
+    }
     if (strcmp(key, "gsw_lds_multi") == 0) {
         if (v < 0 || v > 1) return LMG_ERR_ARG;
         g_gs_lds_multi = v;
@@ -684,6 +706,7 @@ int lmg_gsw_tune_get(const char *key)
     if (strcmp(key, "gsw_multi_max_rows") == 0) return g_gs_multi_max_rows;
     if (strcmp(key, "gsw_lds") == 0) return g_gs_lds;
     if (strcmp(key, "gsw_lds_multi") == 0) return g_gs_lds_multi;
+    if (strcmp(key, "gsw_lds9") == 0) return g_gs_lds9;
     return LMG_ERR_ARG;
 }
 
@@ -697,7 +720,7 @@ int lmg_stencil_gs_supported(uint32_t union_mask)
 int64_t lmg_stencil_gs_work_bytes(int64_t n, int32_t line_stride)
 {
     if (n <= 0 || line_stride <= 0) return 0;
-    const int64_t lines = (n + line_stride - 1) / line_stride, nbands = (lines + 63) / 64;
+    const int64_t lines = (n + line_stride - 1) / line_stride, nbands = (lines + 31) / 32;     // (the LDS bands of 9-point operators: 32 lines)
     return 4 * (kMaxSweeps * nbands + 3) + 4;
 }
 
@@ -742,7 +765,7 @@ int lmg_stencil_gs_sweep(int64_t n, int32_t line_stride, const uint8_t *pid, int
         int per_launch = n <= g_gs_multi_max_rows ? g_gs_max_sweeps : 1;
         // bands staged through LDS: one sweep per launch, operators without the upper-right slot, 16-byte aligned vectors (the
         // piece that straddles the end of a vector of odd length is then inside its last 16 bytes), at least one full chunk
-        const bool lds_ok = !(union_mask & 4u) && (union_mask == kMask5 || union_mask == kMask7) && line_stride >= 64 &&
+        const bool lds_ok = (union_mask == kMask5 || union_mask == kMask7 || (union_mask == kMask9 && g_gs_lds9)) && line_stride >= 64 &&
                             lmg_aligned16(x) && lmg_aligned16(b) && (reinterpret_cast<uintptr_t>(pid) & 3u) == 0;
         // (one sweep: 513^2 0.47 ms with LDS bands, 0.83 with register bands; three sweeps pipelined in one launch, LDS bands vs
         // register bands: 513^2 0.63 vs 1.21 ms, 1025^2 1.08 vs 2.58, 2049^2 1.97 vs 7.7, 4097^2 3.9 vs 22.6 -- the LDS bands take
@@ -752,10 +775,11 @@ int lmg_stencil_gs_sweep(int64_t n, int32_t line_stride, const uint8_t *pid, int
         a.sweeps = sweeps - sw < per_launch ? sweeps - sw : per_launch;
         // ticket and progress counters back to zero (a memset node when captured into a hipGraph)
         // (the error flag at [0] is cleared by the caller once and stays set)
+        a.nbands = (use_lds && union_mask == kMask9) ? (a.lines + 31) / 32 : (a.lines + 63) / 64;
         if (hipMemsetAsync(a.work + 1, 0, 4 * (size_t)(a.sweeps * a.nbands + 2), st) != hipSuccess) return LMG_ERR_LAUNCH;
         int rc;
         if (use_lds) {
-            rc = union_mask == kMask5 ? launch_lds<kMask5>(a, st) : launch_lds<kMask7>(a, st);
+            rc = union_mask == kMask5 ? launch_lds<kMask5>(a, st) : union_mask == kMask7 ? launch_lds<kMask7>(a, st) : launch_lds<kMask9>(a, st);
             if (rc != LMG_OK) return rc;
             continue;
         }

@@ -213,13 +213,25 @@ def test_wavefront_gauss_seidel_bit_exact(name):
         ops.set_wavefront_gs_enabled(True)
 
 
-@pytest.mark.parametrize("name", ["poisson2d_300", "seven_point_150", "poisson2d_129", "poisson2d_1100", "ragged_lines_77x203"])
+@pytest.mark.parametrize("name", ["poisson2d_300", "seven_point_150", "poisson2d_129", "poisson2d_1100", "ragged_lines_77x203",
+                                  "galerkin9_151", "galerkin9_333", "galerkin9_ragged_70x151"])
 def test_gauss_seidel_bands_staged_through_lds_bit_exact(name):
     """gs_band_lds_kernel (the band's lines in 16-column chunks through LDS-DMA, results written back into the tile,
     coalesced chunk stores; what single sweeps of 5- / 7-point operators run beyond the Infinity Cache) forced on small
     grids: one band and many, partial last band, line strides that are no multiple of the chunk, a last line shorter
-    than the others -- against pyamg's sweep restated in oracle/lmg_oracle.c, bitwise, and against the register kernel."""
-    if name == "poisson2d_300":
+    than the others; 9-point Galerkin operators (two columns of skew per lane, 32-line bands: one band, several, a partial
+    last band, a short last line) -- against pyamg's sweep restated in oracle/lmg_oracle.c, bitwise, and against the register
+    kernel; 1 - 3 sweeps pipelined in one launch."""
+    if name.startswith("galerkin9_"):
+        side = {"galerkin9_151": 151, "galerkin9_333": 333, "galerkin9_ragged_70x151": 151}[name]
+        Af = P.poisson_2d_structured(2 * (side - 1))[0]
+        Pf = P.tensor_interpolator_2d(2 * (side - 1) + 1)
+        A = sp.csr_matrix(Pf.T @ Af @ Pf)
+        A.sort_indices()
+        if name == "galerkin9_ragged_70x151":
+            A = sp.csr_matrix(A[: 70 * 151 - 3][:, : 70 * 151 - 3])
+        A = K.as_csr(A)
+    elif name == "poisson2d_300":
         A = K.as_csr(P.poisson_2d_structured(299)[0])
     elif name == "poisson2d_1100":
         A = K.as_csr(P.poisson_2d_structured(1099)[0])
@@ -234,7 +246,8 @@ def test_gauss_seidel_bands_staged_through_lds_bit_exact(name):
     n = A.shape[0]
     dA = ops.DeviceCSR.from_scipy(A, DEV)
     dA.pack()
-    assert dA.stencil is not None and ops.stencil_gs_available(dA) and not (dA.stencil.umask & 4) and dA.stencil.W >= 64, name
+    assert dA.stencil is not None and ops.stencil_gs_available(dA) and dA.stencil.W >= 64, name
+    assert bool(dA.stencil.umask & 4) == name.startswith("galerkin9_"), (name, hex(dA.stencil.umask))
     rng = np.random.default_rng(43)
     x0, b = rng.standard_normal(n), rng.standard_normal(n)
     want = x0.copy()

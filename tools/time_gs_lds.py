@@ -4,8 +4,14 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from learnmultigrid_amd import ops, problems as P
+import scipy.sparse as sp
+NINE = len(sys.argv) > 2 and sys.argv[2] == "9pt"       # python tools/time_gs_lds.py 512,1024,2048 9pt: the 9-point Galerkin operator
 for m in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "512,1024,2048,4096").split(",")]:
-    A, _ = P.poisson_2d_structured(m)
+    if NINE:
+        Af = P.poisson_2d_structured(2 * m)[0]; Pf = P.tensor_interpolator_2d(2 * m + 1)
+        A = sp.csr_matrix(Pf.T @ Af @ Pf); A.sort_indices()
+    else:
+        A, _ = P.poisson_2d_structured(m)
     n = A.shape[0]
     dA = ops.DeviceCSR.from_scipy(A, "cuda:0"); dA.pack()
     rng = np.random.default_rng(1)
@@ -29,5 +35,5 @@ for m in [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "512,1024,2048,
     same3 = torch.equal(xl, x)
     ops.tune_set("gsw_lds", -1)
     print("   3 sweeps pipelined, LDS bands: %.3f ms (equal bits: %s)" % (t3l * 1e3, same3))
-    print("5pt %d^2: one sweep register wavefront %.3f ms, LDS bands %.3f ms (equal bits: %s); 3 sweeps pipelined (register kernel) %.3f ms"
+    print(("9pt" if NINE else "5pt") + " %d^2: one sweep register wavefront %.3f ms, LDS bands %.3f ms (equal bits: %s); 3 sweeps pipelined (register kernel) %.3f ms"
           % (m + 1, res[0][0] * 1e3, res[1][0] * 1e3, torch.equal(res[0][1], res[1][1]), t3 * 1e3), flush=True)

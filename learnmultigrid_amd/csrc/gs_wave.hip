@@ -320,8 +320,8 @@ __global__ void __launch_bounds__(64) gs_wavefront_kernel(GArgs a)
 // ring of 8 chunk slots (65 lines of x, 64 of b, the pattern ids, the last line of the band above) holds the window the
 // 64 skewed lanes work in, results are written back INTO the tile and a finished chunk leaves by 8 coalesced stores.
 // A step then touches LDS only; the band above is waited for once per chunk (its progress counter now counts flushed
-// chunks).  Single sweeps of operators without the upper-right slot (5-point, 7-point: lane l relaxes column t - l).
-// Same row arithmetic in the same order as gs_wavefront_kernel: bit-identical.
+// chunks).  5- and 7-point operators: lane l relaxes column t - l, 64-line bands; 9-point operators (upper-right slot): column
+// t - 2 l, 32-line bands (see SK / NL below).  Same row arithmetic in the same order as gs_wavefront_kernel: bit-identical.
 constexpr int kCW = 16;                                    // columns per chunk
 constexpr int kNCH = 8;                                    // ring slots
 constexpr int kXSBytes = 72 * 128;                         // x: 9 groups of 8 lines (65 used) x 16 columns
@@ -763,8 +763,8 @@ int lmg_stencil_gs_sweep(int64_t n, int32_t line_stride, const uint8_t *pid, int
         // per lane and iteration straight from memory), which costs more than the saved pipeline fills beyond it
         // (3 sweeps: 513^2 1.19 vs 2.43 ms, 1025^2 2.40 vs 4.80, 2049^2 7.2 vs 10.4, 3073^2 15.1 vs 16.0, 4097^2 26.8 vs 22.4)
         int per_launch = n <= g_gs_multi_max_rows ? g_gs_max_sweeps : 1;
-        // bands staged through LDS: one sweep per launch, operators without the upper-right slot, 16-byte aligned vectors (the
-        // piece that straddles the end of a vector of odd length is then inside its last 16 bytes), at least one full chunk
+        // bands staged through LDS: 5- / 7- / 9-point operators, 16-byte aligned vectors (the piece that straddles the end of a
+        // vector of odd length is then inside its last 16 bytes), at least one full chunk per line
         const bool lds_ok = (union_mask == kMask5 || union_mask == kMask7 || (union_mask == kMask9 && g_gs_lds9)) && line_stride >= 64 &&
                             lmg_aligned16(x) && lmg_aligned16(b) && (reinterpret_cast<uintptr_t>(pid) & 3u) == 0;
         // (one sweep: 513^2 0.47 ms with LDS bands, 0.83 with register bands; three sweeps pipelined in one launch, LDS bands vs

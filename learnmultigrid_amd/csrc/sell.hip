@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(kBlock) sell_fill_kernel(int64_t n, int64_t ns
 
 // measured (tools/time_sell.py, Jacobi sweep): 2049^2 x 25 entries (1.05 GB) 0.264 -> 0.250 ms, 1025^2 x 49 (0.51 GB)
 // 0.122 -> 0.114 ms, but 721^2 x 25 (0.13 GB: the whole matrix stays in the Infinity Cache) 0.025 -> 0.032 ms
+int g_sell_ju = 0;                        // entries of a row in flight: 0 = by the longest row (5, 7 or 8); 5, 7, 8, 10 forced
 int g_sell_nt = -1;                       // -1: by size, 0: never, 1: always
 int64_t g_sell_nt_entries = 30000000;     // padded entries from which the streams no longer fit the 256 MB Infinity Cache
 
@@ -197,7 +198,28 @@ int launch(SArgs a, int max_len, hipStream_t st)
     // measured on MI355X (tools/tune_sweep.py --matrix L1|L2): see DESIGN.md
     const dim3 grid((unsigned)(a.blocks_per_xcd * 8)), block(kBlock);
     const bool nt = g_sell_nt == 1 || (g_sell_nt < 0 && (int64_t)a.n * max_len >= g_sell_nt_entries);
+    // entries of a row in flight: the factor that leaves the fewest idle slots in the last trip over the longest row (25-entry
+    // rows: 5 trips of 5 instead of 4 of 8 -- 2049^2 x 25: 0.2505 -> 0.2290 ms; 49: 7 x 7 -- 1025^2 x 49: 0.1057 -> 0.0982 ms)
+    int ju = g_sell_ju;
+    if (ju == 0) {
+        ju = 8;
+        int waste = (8 - max_len % 8) % 8;
+        const int cand[2] = {7, 5};
+        for (int k = 0; k < 2; ++k) {
+            const int w = (cand[k] - max_len % cand[k]) % cand[k];
+            if (w < waste) {
+                waste = w;
+                ju = cand[k];
+            }
+        }
+    }
     if (max_len <= 12) hipLaunchKernelGGL((sell_sweep_kernel<MODE, COL16, 4>), grid, block, 0, st, a);
+    else if (ju == 5 && nt) hipLaunchKernelGGL((sell_sweep_kernel<MODE, COL16, 5, true>), grid, block, 0, st, a);
+    else if (ju == 5) hipLaunchKernelGGL((sell_sweep_kernel<MODE, COL16, 5>), grid, block, 0, st, a);
+    else if (ju == 7 && nt) hipLaunchKernelGGL((sell_sweep_kernel<MODE, COL16, 7, true>), grid, block, 0, st, a);
+    else if (ju == 7) hipLaunchKernelGGL((sell_sweep_kernel<MODE, COL16, 7>), grid, block, 0, st, a);
+    else if (ju == 10 && nt) hipLaunchKernelGGL((sell_sweep_kernel<MODE, COL16, 10, true>), grid, block, 0, st, a);
+    else if (ju == 10) hipLaunchKernelGGL((sell_sweep_kernel<MODE, COL16, 10>), grid, block, 0, st, a);
     else if (nt) hipLaunchKernelGGL((sell_sweep_kernel<MODE, COL16, 8, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((sell_sweep_kernel<MODE, COL16, 8>), grid, block, 0, st, a);
     LMG_CHECK_LAUNCH();
@@ -213,11 +235,17 @@ int lmg_sell_tune_set(const char *key, int v)
         g_sell_nt = v;
         return LMG_OK;
     }
+    if (strcmp(key, "sell_ju") == 0) {
+        if (v != 0 && v != 5 && v != 7 && v != 8 && v != 10) return LMG_ERR_ARG;
+        g_sell_ju = v;
+        return LMG_OK;
+    }
     return LMG_ERR_ARG;
 }
 int lmg_sell_tune_get(const char *key)
 {
     if (strcmp(key, "sell_nt") == 0) return g_sell_nt;
+    if (strcmp(key, "sell_ju") == 0) return g_sell_ju;
     return LMG_ERR_ARG;
 }
 

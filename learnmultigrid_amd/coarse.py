@@ -46,6 +46,7 @@ def csr_to_dense(A):
     return dense
 
 
+GRID_G_FORCE = None           # grid-block solver: blocks per line instead of the byte-minimal choice (A/B: tools/scan_coarse.py)
 FOLD_PERMUTATION = True       # banded solver: gather / scatter folded into the first / last product (A/B switch)
 BACKSUB_ONE_LAUNCH = True     # banded solver: x_I = y_I - (A_II^-1 A_IS) x_S instead of A_II^-1 (b_I - A_IS x_S)
 
@@ -471,7 +472,7 @@ class GridBlockSolver:
     def plan(cls, W, lines, r):
         """(Gy, Gx, dense bytes per application) minimising k s^2 + k s cw + nS^2, or None."""
         best = None
-        for G in range(2, 65):
+        for G in (range(2, 65) if GRID_G_FORCE is None else (int(GRID_G_FORCE),)):
             Gx = G
             Gy = max(2, int(round(G * lines / W)))
             lx, ly = cls._cuts(W, Gx, r), cls._cuts(lines, Gy, r)

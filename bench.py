@@ -91,7 +91,7 @@ def parse():
     ap.add_argument("--mode", default="vcycle", choices=["vcycle", "sweep"])
     ap.add_argument("--no-graph", action="store_true", help="launch kernels from Python instead of replaying a hipGraph")
     ap.add_argument("--variant", type=int, default=-1, help="sweep kernel tile variant (-1 = library default)")
-    ap.add_argument("--cpu-cycles", type=int, default=2, help="V-cycles timed by the CPU baseline leg")
+    ap.add_argument("--cpu-cycles", type=int, default=10, help="V-cycles timed by the CPU baseline leg (about 10 s of one core)")
     ap.add_argument("--problem", default="poisson", choices=["poisson", "varcoeff", "jittered"],
                     help="poisson = cfg#2/#4 (default), varcoeff = cfg#5, jittered = cfg#3 (7-point)")
     ap.add_argument("--transfer", default="geometric", choices=["geometric", "learned"],

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Randomised bitwise comparison of the LDS-staged Gauss-Seidel bands (single and pipelined sweeps, 5- and 9-point operators)
 with the register wavefront kernel and -- on the small cases -- with the sequential CPU sweep of oracle/lmg_oracle.c.
-    python tools/fuzz_gs.py --cases 40 --seed 1"""
+    python tests/fuzz_gs.py --cases 40 --seed 1   (under tests/: it uses the oracle as the checker)"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, scipy.sparse as sp, torch
 from learnmultigrid_amd import ops, problems as P
-from oracle import kernels as K          # (a tool: the checker, never the product path)
+from oracle import kernels as K
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--cases", type=int, default=30)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time one exact (lexicographic) Gauss-Seidel sweep on the reference's typical problems.
-`python tools/time_gs.py big` times the large 2-D grids with both executors (per-set launches
+`python tests/time_gs.py big` times the large 2-D grids with both executors (per-set launches
 and the one-workgroup persistent kernel)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
